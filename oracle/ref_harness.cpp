@@ -1,0 +1,112 @@
+// oracle/ref_harness.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// Thin extern "C" doors onto the REAL reference code, compiled in place from
+// /root/reference (see oracle/Makefile, target _ref/libref.so):
+//   * src/Intersect.cpp          Triangle / Plane / BoxObject / Sphere ::intersects
+//   * src/Ray.h                  Ray ctor, reflectRay, refractRay, resendRay
+//   * tucano/camera.hpp          Tucano::Camera::screenToWorld / getCenter
+//   * Eigen 3.3.7 (vendored)     normalized / cross / Affine inverse, as used by
+//                                tucano/mesh.hpp:461-463 and src/flyscene.cpp:839
+// Nothing of the reference is copied: this file only *calls* it.  flyscene.cpp
+// itself cannot be linked here without GL/GLEW/GLFW libraries (absent in the
+// image), so the drivers above these primitives (getIntersections, traceRay,
+// calculateColor ...) are validated through oracle/rt_oracle.c, whose primitive
+// arithmetic is pinned bit-for-bit against this library.
+#include <cmath>
+#include <vector>
+#include <iostream>
+#include "Intersect.h"          // reference src/Intersect.h (pulls Ray.h, hitInfo.h, box.h)
+#include <tucano/camera.hpp>    // reference dependencies/tucano
+
+using Eigen::Vector3f;
+static inline Vector3f V(const float* p) { return Vector3f(p[0], p[1], p[2]); }
+static inline void S(float* p, const Vector3f& v) { p[0] = v[0]; p[1] = v[1]; p[2] = v[2]; }
+
+extern "C" {
+
+// Ray::Ray  (src/Ray.h:15-18)
+void ref_ray(const float* o, const float* d, float* out_o, float* out_d) {
+  Ray r(V(o), V(d)); S(out_o, r.getOrigin()); S(out_d, r.getDirection());
+}
+// Intersect::Triangle::intersects  (src/Intersect.cpp:6-46). hit = {t, nx,ny,nz, px,py,pz}
+void ref_triangle(const float* o, const float* d, const float* v0, const float* v1,
+                  const float* v2, const float* n, float* hit) {
+  Ray r(V(o), V(d));
+  std::vector<Vector3f> v{V(v0), V(v1), V(v2)};
+  Intersect::Triangle t(v, V(n));
+  HitInfo h = t.intersects(r);
+  hit[0] = h.t; S(hit + 1, h.normal); S(hit + 4, h.point);
+}
+// Intersect::Plane::intersects  (src/Intersect.cpp:48-64)
+void ref_plane(const float* o, const float* d, const float* v0, const float* n, float* hit) {
+  Ray r(V(o), V(d));
+  std::vector<Vector3f> v{V(v0)};
+  Intersect::Plane t(v, V(n));
+  HitInfo h = t.intersects(r);
+  hit[0] = h.t; S(hit + 1, h.normal); S(hit + 4, h.point);
+}
+// Intersect::BoxObject::intersects  (src/Intersect.cpp:67-145)
+float ref_box(const float* o, const float* d, const float* bmin, const float* bmax) {
+  Ray r(V(o), V(d));
+  Box b(V(bmin), V(bmax));
+  Intersect::BoxObject bo(b);
+  return bo.intersects(r).t;
+}
+// Intersect::Sphere::intersects  (src/Intersect.cpp:147-193)
+void ref_sphere(const float* o, const float* d, const float* c, float radius, float* hit) {
+  Ray r(V(o), V(d));
+  Intersect::Sphere s(V(c), radius);
+  HitInfo h = s.intersects(r);
+  hit[0] = h.t; S(hit + 1, h.normal); S(hit + 4, h.point);
+}
+// Ray::reflectRay  (src/Ray.h:32-35)
+void ref_reflect(const float* o, const float* d, const float* n, const float* p,
+                 float* out_o, float* out_d) {
+  Ray r(V(o), V(d)); Ray q = r.reflectRay(V(n), V(p));
+  S(out_o, q.getOrigin()); S(out_d, q.getDirection());
+}
+// Ray::refractRay  (src/Ray.h:36-42)
+void ref_refract(const float* o, const float* d, const float* n, const float* p,
+                 const float* view, float n1, float n2, float* out_o, float* out_d) {
+  Ray r(V(o), V(d)); Ray q = r.refractRay(V(n), V(p), V(view), n1, n2);
+  S(out_o, q.getOrigin()); S(out_d, q.getDirection());
+}
+// Ray::resendRay  (src/Ray.h:43-57). out_d holds 3*count floats.
+void ref_resend(const float* o, const float* d, const float* n, const float* p, int count,
+                float* out_d) {
+  Ray r(V(o), V(d)); std::vector<Ray> q = r.resendRay(V(n), V(p), count);
+  for (int i = 0; i < count; ++i) S(out_d + 3 * i, q[i].getDirection());
+}
+// Face normal exactly as Tucano::Mesh::createFaces forms it (tucano/mesh.hpp:461-463).
+void ref_face_normal(const float* a, const float* b, const float* c, float* out) {
+  Vector3f v1 = (V(c) - V(a)).normalized();
+  Vector3f v0 = (V(b) - V(a)).normalized();
+  S(out, (v0.cross(v1)).normalized());
+}
+// Normal re-derivation of Flyscene::intersectTriangle (src/flyscene.cpp:839) with the
+// identity shape-model matrix the reference always has.
+void ref_renormal(const float* n, float* out) {
+  Eigen::Affine3f M = Eigen::Affine3f::Identity() * Eigen::Affine3f::Identity();
+  Vector3f r = (M.inverse().matrix().transpose() * Eigen::Vector4f(n[0], n[1], n[2], 0)).head<3>().normalized();
+  S(out, r);
+}
+float ref_dot(const float* a, const float* b) { return V(a).dot(V(b)); }
+float ref_norm(const float* a) { return V(a).norm(); }
+void ref_normalized(const float* a, float* out) { S(out, V(a).normalized()); }
+// Shader::reflect (src/ShaderLib.h:7-9) cannot be included (it includes "Flyscene.hpp",
+// which does not exist under that case); the same Eigen expression shape is in Ray.h:33.
+
+// Tucano::Camera::screenToWorld / getCenter  (tucano/camera.hpp:115-118,155-173).
+// view = 12 floats, row-major 3x4 [R|t]; vp = {w,h}.
+void ref_camera(const float* view, float vw, float vh, float fovy, float aspect,
+                float i, float j, float* world, float* center) {
+  Tucano::Camera cam;
+  Eigen::Affine3f vm = Eigen::Affine3f::Identity();
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) vm.matrix()(r, c) = view[4 * r + c];
+  cam.setViewMatrix(vm);
+  cam.setPerspectiveMatrix(fovy, aspect, 0.1f, 100.0f);
+  cam.setViewport(Eigen::Vector2f(vw, vh));
+  S(world, cam.screenToWorld(Eigen::Vector2f(i, j)));
+  S(center, cam.getCenter());
+}
+}  // extern "C"
