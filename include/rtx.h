@@ -1,0 +1,142 @@
+/* include/rtx.h -- C ABI of librtx.so, the MI355X (gfx950) ray-scene intersection engine.
+ *
+ * This is the drop-in boundary for the Raytracing-Project hot path: every entry point
+ * names the reference interface it replaces (paths relative to the reference repo).
+ * Plain pointers and sizes only; no C++/torch types.  All functions return 0 on success
+ * or a negative RTX_E* code; rtx_last_error() gives the message for the calling thread.
+ *
+ * Pointer residency: entry points ending in `_dev` take DEVICE pointers (hipMalloc'd or
+ * torch.cuda tensors on the scene's device) and run asynchronously on the scene's stream
+ * followed by a stream synchronise; all others take HOST pointers.
+ *
+ * Threading: calls on one rtx_scene are serialised by the caller; different scenes are
+ * independent (one HIP stream each).  The reference mutates its scene only between
+ * renders (src/main.cpp:63-77); so does this API (mutators need a new rtx_scene_commit).
+ */
+#ifndef RTX_H
+#define RTX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTX_OK 0
+#define RTX_EINVAL (-1)    /* bad argument */
+#define RTX_ESTATE (-2)    /* scene not committed / already committed */
+#define RTX_EHIP (-3)      /* HIP runtime error (no device, out of memory, launch failure) */
+#define RTX_ELIMIT (-4)    /* size beyond a documented limit */
+
+typedef struct rtx_scene rtx_scene;
+
+/* Tucano::Material::Mtl (dependencies/tucano/tucano/materials/mtl.hpp:16-116). */
+typedef struct {
+  float ka[3], kd[3], ks[3];
+  float ns;        /* shininess */
+  float ni;        /* optical density */
+  float d;         /* dissolve factor */
+  int32_t illum;
+} rtx_material;
+
+/* The state Tucano::Camera::screenToWorld / getCenter read
+ * (dependencies/tucano/tucano/camera.hpp:42-78,115-118,155-173,263-266). */
+typedef struct {
+  float view[12];      /* row-major 3x4 [R|t] of the Affine3f view matrix */
+  float viewport[4];   /* minX, minY, width, height */
+  float fovy;          /* degrees */
+  float aspect;        /* width / height as set by setPerspectiveMatrix */
+  float subpixel[2];   /* added to the raster (i,j); (0,0) = the reference's top-left sample */
+} rtx_camera;
+
+/* Compile-time switches of the reference made run-time (src/flyscene.cpp:11,704 and the
+ * unconditional reflect/refract/shadow calls at :686-723).  The reference itself is
+ * {2, 1, 1, 8, 1, 0}.  refraction/gi_rays other than 0 are rejected by rtx_render until
+ * the full calculateColor fidelity row lands. */
+typedef struct {
+  int32_t max_bounces;
+  int32_t reflection;
+  int32_t refraction;
+  int32_t gi_rays;
+  int32_t shadows;
+  int32_t skip_zero_weight;  /* do not trace a child ray whose blend weight is exactly 0 */
+} rtx_options;
+
+typedef struct { int32_t x0, y0, x1, y1; } rtx_rect;   /* pixel rectangle [x0,x1) x [y0,y1) */
+
+/* Counters of the last trace/render call on a scene. */
+typedef struct {
+  uint64_t rays_primary, rays_shadow, rays_reflection, rays_refraction, rays_gi;
+  float ms_trace;      /* HIP-event time of the traversal kernels (sum over launches) */
+  float ms_total;      /* HIP-event time of every kernel of the call */
+  uint32_t launches_trace;
+  uint32_t reserved;
+} rtx_stats;
+
+typedef struct {
+  uint32_t ntris, nverts, nnodes, nleaves, max_depth, nspheres, nlights, nmaterials;
+  uint64_t device_bytes;
+  float build_ms;
+} rtx_scene_info;
+
+const char* rtx_last_error(void);
+int rtx_device_count(void);
+
+/* Replaces the scene state Flyscene::initialize builds from a Tucano::Mesh
+ * (src/flyscene.cpp:13-120; vertices/faces: dependencies/tucano/tucano/mesh.hpp:238-247,
+ * 441-468).  Triangles keep the caller's order: face ids returned by queries are indices
+ * into tri_idx, exactly like HitInfo::faceId over root_box.triangles.
+ * tri_material may be NULL (all -1). */
+int rtx_scene_create(const float* verts_xyz, uint32_t nverts, const uint32_t* tri_idx,
+                     const int32_t* tri_material, uint32_t ntris, const rtx_material* mats,
+                     uint32_t nmats, rtx_scene** out);
+int rtx_scene_destroy(rtx_scene*);
+
+/* materials.push_back (src/flyscene.cpp:455-456); returns the new id (>= 0). */
+int rtx_scene_add_material(rtx_scene*, const rtx_material*);
+/* Scene::addSphere (src/Scene.h:36-49): center + the radius as stored (already / 3). */
+int rtx_scene_set_spheres(rtx_scene*, const float* center_radius4, const int32_t* material, uint32_t n);
+/* Flyscene::lights / sphericalLights (src/flyscene.hpp:140-141, addLight :61-62). */
+int rtx_scene_set_lights(rtx_scene*, const float* xyz, uint32_t n, const float* sphere_xyzr, uint32_t m);
+
+/* Replaces Box(mesh) + divideBox_KD (src/box.h:41-85, src/flyscene.cpp:77-82,1110-1185).
+ * rtx_scene_build flattens the mesh into per-triangle records (reference arithmetic) and
+ * builds the linear BVH on the host; it needs no GPU.  rtx_scene_commit builds if needed
+ * and uploads everything to `device`. */
+int rtx_scene_build(rtx_scene*);
+int rtx_scene_commit(rtx_scene*, int device);
+int rtx_scene_get_info(const rtx_scene*, rtx_scene_info*);
+/* Host copy of the flattened acceleration structure (tests / roofline accounting).
+ * nodes: nnodes x 8 words {lo.xyz, leftOrFirst, hi.xyz, count}; tri_face: ntris ids in leaf order. */
+int rtx_scene_get_bvh(const rtx_scene*, uint32_t* nodes8, uint32_t* tri_face);
+/* Host copy of the leaf-ordered 64-byte triangle records: ntris x 16 floats
+ * {v0.xyz, D}{u.xyz, u.u}{v.xyz, u.v}{n.xyz, v.v} (src/Intersect.cpp:10,26-32 hoisted per triangle). */
+int rtx_scene_get_tris(const rtx_scene*, float* tri16);
+
+/* Flyscene::getIntersections(Ray(o,d)) for n rays (src/flyscene.cpp:517-585): closest hit
+ * over spheres, then the root-box gate and every triangle; face_id = mesh face index
+ * (-1 for spheres and misses), t = INFINITY on a miss.  normal/point/material may be NULL. */
+int rtx_trace_closest(rtx_scene*, const float* origin_xyz, const float* dir_xyz, uint32_t n,
+                      float* t, int32_t* face_id, float* normal_xyz, float* point_xyz,
+                      int32_t* material);
+int rtx_trace_closest_dev(rtx_scene*, const float* origin_xyz, const float* dir_xyz, uint32_t n,
+                          float* t, int32_t* face_id);
+
+/* Flyscene::canSeeLight(lightPos, position) for n pairs (src/flyscene.cpp:747-782).
+ * blocker_material: material id the reference would return, -1 for the default Mtl. */
+int rtx_trace_visible(rtx_scene*, const float* light_xyz, const float* position_xyz, uint32_t n,
+                      uint8_t* visible, int32_t* blocker_material);
+
+/* Flyscene::updating_pixels / raytraceScene over a pixel rectangle
+ * (src/flyscene.cpp:395-468): camera ray -> traceRay(0, ray, false) per pixel.
+ * Outputs are row-major [y - y0][x - x0]; any of rgb (3 floats/pixel), t, face_id may be NULL. */
+int rtx_render(rtx_scene*, const rtx_camera*, const rtx_options*, rtx_rect rect,
+               float* rgb, float* t, int32_t* face_id);
+int rtx_render_dev(rtx_scene*, const rtx_camera*, const rtx_options*, rtx_rect rect,
+                   float* rgb, float* t, int32_t* face_id);
+
+int rtx_get_stats(const rtx_scene*, rtx_stats*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

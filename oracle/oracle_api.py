@@ -110,8 +110,44 @@ def lib():
         L.ora_resend.argtypes = [_f, _f, _f, _f, C.c_int, _f]
         L.ora_points_on_circle.argtypes = [_f, C.c_float, _f, C.c_int, _f]
         L.ora_points_on_circle.restype = C.c_int
+        L.ora_bvh_trace.argtypes = [C.POINTER(C.c_uint32), _f, C.POINTER(C.c_int32), C.c_uint32, _f, _f, _f, _f,
+                                    C.c_int, C.c_int, _f, C.POINTER(C.c_int32), C.POINTER(C.c_uint32),
+                                    C.POINTER(C.c_uint32)]
+        L.ora_bvh_trace.restype = None
+        L.ora_camera_rays.argtypes = [C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, _f, _f]
+        L.ora_camera_rays.restype = None
         _lib = L
     return _lib
+
+
+def bvh_trace(nodes8, tri16, tri_face, root_lo, root_hi, o, d1, threads=1):
+    """CPU mirror of the GPU traversal over the BVH exported by librtx: (t, face, nodes_visited, tris_tested)."""
+    nodes8 = np.ascontiguousarray(nodes8, np.uint32)
+    tri16 = np.ascontiguousarray(tri16, np.float32)
+    tri_face = np.ascontiguousarray(tri_face, np.int32)
+    o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+    d1 = np.ascontiguousarray(d1, np.float32).reshape(-1, 3)
+    rl = np.ascontiguousarray(root_lo, np.float32)
+    rh = np.ascontiguousarray(root_hi, np.float32)
+    n = len(o)
+    t = np.zeros(n, np.float32)
+    face = np.zeros(n, np.int32)
+    nv = np.zeros(n, np.uint32)
+    tt = np.zeros(n, np.uint32)
+    lib().ora_bvh_trace(nodes8.ctypes.data_as(C.POINTER(C.c_uint32)), fp(tri16),
+                        tri_face.ctypes.data_as(C.POINTER(C.c_int32)), len(tri_face), fp(rl), fp(rh), fp(o), fp(d1),
+                        n, threads, fp(t), face.ctypes.data_as(C.POINTER(C.c_int32)),
+                        nv.ctypes.data_as(C.POINTER(C.c_uint32)), tt.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return t, face, nv, tt
+
+
+def camera_rays(cam, rect):
+    x0, y0, x1, y1 = rect
+    n = (x1 - x0) * (y1 - y0)
+    o = np.zeros((n, 3), np.float32)
+    d1 = np.zeros((n, 3), np.float32)
+    lib().ora_camera_rays(C.byref(cam), x0, y0, x1, y1, fp(o), fp(d1))
+    return o, d1
 
 
 def ref():

@@ -1,0 +1,164 @@
+/* oracle/rt_oracle_bvh.c -- TEST / MEASUREMENT INFRASTRUCTURE ONLY.
+ *
+ * CPU single-ray ordered traversal of the linear BVH exported by librtx
+ * (rtx_scene_get_bvh / rtx_scene_get_tris).  Two uses:
+ *   1. host-logic test without a GPU: BVH traversal == brute force (oracle) on every ray;
+ *   2. the node / triangle visit counts behind bench.py's roofline figure
+ *      (algorithmic bytes = 32*nodes_visited + 36*tris_tested + io).
+ * It mirrors closest_hit() of raytracing_project_amd/csrc/rtx_kernels.h step by step
+ * (same near-first order, same culling slab arithmetic, same prune slack), so the counts
+ * are those of the GPU's own traversal order.  Triangle acceptance is the reference test
+ * (src/Intersect.cpp:6-46) on the hoisted per-triangle constants.
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "rt_oracle.h"
+
+#define LEAF_BIT 0x80000000u
+static const float PRUNE_SLACK = 1.0001f;
+
+static inline float dot3f(const float* a, const float* b) { return a[0] * b[0] + (a[1] * b[1] + a[2] * b[2]); }
+static inline void normalize3f(const float* a, float* out) {
+  float z = dot3f(a, a);
+  if (z > 0.0f) { float s = sqrtf(z); out[0] = a[0] / s; out[1] = a[1] / s; out[2] = a[2] / s; }
+  else { out[0] = a[0]; out[1] = a[1]; out[2] = a[2]; }
+}
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+typedef struct {
+  const uint32_t* nodes; const float* tris; const int32_t* tri_face; uint32_t ntris;
+  const float* root_lo; const float* root_hi;
+  const float* o; const float* d1; int n, tid, nthreads;
+  float* t; int32_t* face; uint32_t* nodes_visited; uint32_t* tris_tested;
+} bvh_job;
+
+/* reference root gate: Intersect::BoxObject::intersects (src/Intersect.cpp:67-145) */
+static float gate(const float* o, const float* dir, const float* bmin, const float* bmax) {
+  float ix = 1 / dir[0], iy = 1 / dir[1], iz = 1 / dir[2];
+  float txmin, txmax, tymin, tymax, tzmin, tzmax;
+  if (ix >= 0) { txmin = (bmin[0] - o[0]) * ix; txmax = (bmax[0] - o[0]) * ix; } else { txmin = (bmax[0] - o[0]) * ix; txmax = (bmin[0] - o[0]) * ix; }
+  if (iy >= 0) { tymin = (bmin[1] - o[1]) * iy; tymax = (bmax[1] - o[1]) * iy; } else { tymin = (bmax[1] - o[1]) * iy; tymax = (bmin[1] - o[1]) * iy; }
+  if ((txmin > tymax) || (tymin > txmax)) return INFINITY;
+  if (tymin > txmin) txmin = tymin;
+  if (tymax < txmax) txmax = tymax;
+  if (iz >= 0) { tzmin = (bmin[2] - o[2]) * iz; tzmax = (bmax[2] - o[2]) * iz; } else { tzmin = (bmax[2] - o[2]) * iz; tzmax = (bmin[2] - o[2]) * iz; }
+  if ((txmin > tzmax) || (tzmin > txmax)) return INFINITY;
+  if (tzmin > txmin) txmin = tzmin;
+  return txmin;
+}
+
+static void slab(const uint32_t* node, const float* iv, const float* oi, float* tn, float* tf) {
+  float lo[3] = {u2f(node[0]), u2f(node[1]), u2f(node[2])}, hi[3] = {u2f(node[4]), u2f(node[5]), u2f(node[6])};
+  float a[3], b[3];
+  for (int k = 0; k < 3; ++k) { a[k] = fmaf(lo[k], iv[k], -oi[k]); b[k] = fmaf(hi[k], iv[k], -oi[k]); }
+  *tn = fmaxf(fmaxf(fminf(a[0], b[0]), fminf(a[1], b[1])), fminf(a[2], b[2]));
+  *tf = fminf(fminf(fmaxf(a[0], b[0]), fmaxf(a[1], b[1])), fmaxf(a[2], b[2]));
+}
+
+static void* bvh_worker(void* arg) {
+  bvh_job* j = (bvh_job*)arg;
+  uint32_t stack[64];
+  for (int i = j->tid; i < j->n; i += j->nthreads) {
+    const float* o = j->o + 3 * i;
+    float d[3];
+    normalize3f(j->d1 + 3 * i, d);
+    float best_t = INFINITY; int best_id = -1;
+    uint32_t nv = 0, tt = 0;
+    if (j->ntris && gate(o, d, j->root_lo, j->root_hi) != INFINITY) {
+      float iv[3];
+      for (int k = 0; k < 3; ++k) { iv[k] = 1.0f / d[k]; if (!(fabsf(iv[k]) <= 1e18f)) iv[k] = copysignf(1e18f, d[k]); }
+      float oi[3] = {o[0] * iv[0], o[1] * iv[1], o[2] * iv[2]};
+      const uint32_t* root = j->nodes;
+      uint32_t cur = root[7] ? (LEAF_BIT | (root[7] << 28) | root[3]) : root[3];
+      int sp = 0;
+      for (;;) {
+        if (!(cur & LEAF_BIT)) {
+          const uint32_t* n0 = j->nodes + 8 * (size_t)cur;
+          const uint32_t* n1 = n0 + 8;
+          nv += 2;
+          float lim = best_t * PRUNE_SLACK, tn0, tf0, tn1, tf1;
+          slab(n0, iv, oi, &tn0, &tf0);
+          slab(n1, iv, oi, &tn1, &tf1);
+          int h0 = (tn0 <= tf0) && (tf0 >= 0.0f) && (tn0 <= lim);
+          int h1 = (tn1 <= tf1) && (tf1 >= 0.0f) && (tn1 <= lim);
+          uint32_t e0 = n0[7] ? (LEAF_BIT | (n0[7] << 28) | n0[3]) : n0[3];
+          uint32_t e1 = n1[7] ? (LEAF_BIT | (n1[7] << 28) | n1[3]) : n1[3];
+          if (h0 && h1) {
+            int first0 = tn0 <= tn1;
+            stack[sp++] = first0 ? e1 : e0;
+            cur = first0 ? e0 : e1;
+            continue;
+          }
+          if (h0) { cur = e0; continue; }
+          if (h1) { cur = e1; continue; }
+        } else {
+          uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
+          for (uint32_t k = first; k < first + cnt; ++k) {
+            const float* q = j->tris + 16 * (size_t)k;
+            ++tt;
+            const float* nrm = q + 12;
+            float den = dot3f(nrm, d);
+            if (den != 0.0f) {
+              float t = (q[3] - dot3f(o, nrm)) / den;
+              if (t >= 0.001f && t <= best_t) {
+                float P[3] = {o[0] + t * d[0], o[1] + t * d[1], o[2] + t * d[2]};
+                float w[3] = {P[0] - q[0], P[1] - q[1], P[2] - q[2]};
+                float wu = dot3f(w, q + 4), wv = dot3f(w, q + 8);
+                float uu = q[7], uv = q[11], vv = q[15];
+                float denom = uu * vv - uv * uv;
+                float s1 = vv * wu - uv * wv, t1 = uu * wv - uv * wu;
+                float s = s1 / denom, tb = t1 / denom;
+                if (!(s < 0 || tb < 0 || s + tb > 1)) {
+                  int face = j->tri_face[k];
+                  if (t < best_t || (t == best_t && face < best_id)) { best_t = t; best_id = face; }
+                }
+              }
+            }
+          }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+      }
+    }
+    j->t[i] = best_t; j->face[i] = best_id;
+    if (j->nodes_visited) j->nodes_visited[i] = nv;
+    if (j->tris_tested) j->tris_tested[i] = tt;
+  }
+  return NULL;
+}
+
+/* d1 = the direction a Ray object holds (already normalised once); triangles only, no spheres. */
+void ora_bvh_trace(const uint32_t* nodes8, const float* tri16, const int32_t* tri_face, uint32_t ntris,
+                   const float* root_lo, const float* root_hi, const float* o, const float* d1, int n, int threads,
+                   float* t, int32_t* face, uint32_t* nodes_visited, uint32_t* tris_tested) {
+  if (threads < 1) threads = 1;
+  if (threads > 256) threads = 256;
+  bvh_job jobs[256];
+  pthread_t th[256];
+  for (int i = 0; i < threads; ++i) {
+    bvh_job* j = &jobs[i];
+    j->nodes = nodes8; j->tris = tri16; j->tri_face = tri_face; j->ntris = ntris; j->root_lo = root_lo; j->root_hi = root_hi;
+    j->o = o; j->d1 = d1; j->n = n; j->tid = i; j->nthreads = threads; j->t = t; j->face = face;
+    j->nodes_visited = nodes_visited; j->tris_tested = tris_tested;
+  }
+  if (threads == 1) { bvh_worker(&jobs[0]); return; }
+  for (int i = 0; i < threads; ++i) pthread_create(&th[i], NULL, bvh_worker, &jobs[i]);
+  for (int i = 0; i < threads; ++i) pthread_join(th[i], NULL);
+}
+
+/* Primary-ray directions of a camera over a pixel rectangle, as Ray objects hold them (d1). */
+void ora_camera_rays(const ora_camera* cam, int x0, int y0, int x1, int y1, float* o, float* d1) {
+  int W = x1 - x0;
+  for (int y = y0; y < y1; ++y)
+    for (int x = x0; x < x1; ++x) {
+      float w[3], c[3], dir[3];
+      ora_camera_point(cam, (float)x + cam->sub[0], (float)y + cam->sub[1], w, c);
+      dir[0] = w[0] - c[0]; dir[1] = w[1] - c[1]; dir[2] = w[2] - c[2];
+      size_t k = (size_t)(y - y0) * W + (x - x0);
+      o[3 * k] = c[0]; o[3 * k + 1] = c[1]; o[3 * k + 2] = c[2];
+      normalize3f(dir, d1 + 3 * k);
+    }
+}

@@ -1,0 +1,228 @@
+"""ctypes binding of include/rtx.h.  Fails loudly when librtx.so is missing."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librtx.so")
+
+_f = C.POINTER(C.c_float)
+_i = C.POINTER(C.c_int32)
+_u = C.POINTER(C.c_uint32)
+
+
+class Material(C.Structure):
+    _fields_ = [("ka", C.c_float * 3), ("kd", C.c_float * 3), ("ks", C.c_float * 3),
+                ("ns", C.c_float), ("ni", C.c_float), ("d", C.c_float), ("illum", C.c_int32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("view", C.c_float * 12), ("viewport", C.c_float * 4), ("fovy", C.c_float),
+                ("aspect", C.c_float), ("subpixel", C.c_float * 2)]
+
+
+class Options(C.Structure):
+    _fields_ = [("max_bounces", C.c_int32), ("reflection", C.c_int32), ("refraction", C.c_int32),
+                ("gi_rays", C.c_int32), ("shadows", C.c_int32), ("skip_zero_weight", C.c_int32)]
+
+
+class Rect(C.Structure):
+    _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_reflection", C.c_uint64),
+                ("rays_refraction", C.c_uint64), ("rays_gi", C.c_uint64), ("ms_trace", C.c_float),
+                ("ms_total", C.c_float), ("launches_trace", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [("ntris", C.c_uint32), ("nverts", C.c_uint32), ("nnodes", C.c_uint32), ("nleaves", C.c_uint32),
+                ("max_depth", C.c_uint32), ("nspheres", C.c_uint32), ("nlights", C.c_uint32),
+                ("nmaterials", C.c_uint32), ("device_bytes", C.c_uint64), ("build_ms", C.c_float)]
+
+
+# every symbol include/rtx.h declares
+SYMBOLS = ["rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy",
+           "rtx_scene_add_material", "rtx_scene_set_spheres", "rtx_scene_set_lights", "rtx_scene_build", "rtx_scene_commit",
+           "rtx_scene_get_tris",
+           "rtx_scene_get_info", "rtx_scene_get_bvh", "rtx_trace_closest", "rtx_trace_closest_dev",
+           "rtx_trace_visible", "rtx_render", "rtx_render_dev", "rtx_get_stats"]
+
+_lib = None
+
+
+class RtxError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("librtx.so is missing (%s): build it with __graft_entry__.build(); "
+                              "there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.rtx_last_error.restype = C.c_char_p
+        L.rtx_scene_create.argtypes = [_f, C.c_uint32, _u, _i, C.c_uint32, C.POINTER(Material), C.c_uint32,
+                                       C.POINTER(C.c_void_p)]
+        L.rtx_scene_destroy.argtypes = [C.c_void_p]
+        L.rtx_scene_add_material.argtypes = [C.c_void_p, C.POINTER(Material)]
+        L.rtx_scene_set_spheres.argtypes = [C.c_void_p, _f, _i, C.c_uint32]
+        L.rtx_scene_set_lights.argtypes = [C.c_void_p, _f, C.c_uint32, _f, C.c_uint32]
+        L.rtx_scene_commit.argtypes = [C.c_void_p, C.c_int]
+        L.rtx_scene_build.argtypes = [C.c_void_p]
+        L.rtx_scene_get_tris.argtypes = [C.c_void_p, _f]
+        L.rtx_scene_get_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
+        L.rtx_scene_get_bvh.argtypes = [C.c_void_p, _u, _u]
+        L.rtx_trace_closest.argtypes = [C.c_void_p, _f, _f, C.c_uint32, _f, _i, _f, _f, _i]
+        L.rtx_trace_closest_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.rtx_trace_visible.argtypes = [C.c_void_p, _f, _f, C.c_uint32, C.POINTER(C.c_uint8), _i]
+        L.rtx_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Options), Rect, _f, _f, _i]
+        L.rtx_render_dev.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Options), Rect, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]
+        L.rtx_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise RtxError("rtx error %d: %s" % (rc, lib().rtx_last_error().decode()))
+    return rc
+
+
+def make_material(ka=(0.3, 0.3, 0.3), kd=(0.5, 0.5, 0.5), ks=(1.0, 1.0, 1.0), ns=10.0, ni=0.0, d=1.0, illum=0):
+    m = Material()
+    m.ka[:] = ka
+    m.kd[:] = kd
+    m.ks[:] = ks
+    m.ns, m.ni, m.d, m.illum = ns, ni, d, illum
+    return m
+
+
+def make_camera(view34, width, height, fovy=60.0, aspect=None, subpixel=(0.0, 0.0)):
+    c = Camera()
+    c.view[:] = [float(x) for x in np.asarray(view34, np.float32).reshape(12)]
+    c.viewport[:] = [0.0, 0.0, float(width), float(height)]
+    c.fovy = fovy
+    c.aspect = float(np.float32(width) / np.float32(height)) if aspect is None else aspect
+    c.subpixel[:] = subpixel
+    return c
+
+
+def fp(a):
+    return a.ctypes.data_as(_f)
+
+
+class Scene:
+    """Owner of one rtx_scene handle."""
+
+    def __init__(self, verts, idx, tri_mat, mats):
+        L = lib()
+        self.verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
+        self.idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
+        n = len(self.idx)
+        tm = None if tri_mat is None else np.ascontiguousarray(tri_mat, np.int32)
+        arr = (Material * max(1, len(mats)))(*mats)
+        h = C.c_void_p()
+        _check(L.rtx_scene_create(fp(self.verts), len(self.verts), self.idx.ctypes.data_as(_u),
+                                  None if tm is None else tm.ctypes.data_as(_i), n, arr, len(mats), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rtx_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def add_material(self, m):
+        return _check(lib().rtx_scene_add_material(self.h, C.byref(m)))
+
+    def set_spheres(self, center_radius4, mats):
+        cr = np.ascontiguousarray(center_radius4, np.float32).reshape(-1, 4)
+        m = np.ascontiguousarray(mats, np.int32)
+        _check(lib().rtx_scene_set_spheres(self.h, fp(cr), m.ctypes.data_as(_i), len(cr)))
+
+    def set_lights(self, points, sphere_lights=None):
+        p = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+        s = np.zeros((0, 4), np.float32) if sphere_lights is None else \
+            np.ascontiguousarray(sphere_lights, np.float32).reshape(-1, 4)
+        _check(lib().rtx_scene_set_lights(self.h, fp(p), len(p), fp(s), len(s)))
+
+    def build(self):
+        _check(lib().rtx_scene_build(self.h))
+
+    def tris(self):
+        i = self.info()
+        out = np.zeros((max(1, i.ntris), 16), np.float32)
+        _check(lib().rtx_scene_get_tris(self.h, fp(out)))
+        return out[:i.ntris]
+
+    def commit(self, device=0):
+        _check(lib().rtx_scene_commit(self.h, device))
+
+    def info(self):
+        i = SceneInfo()
+        _check(lib().rtx_scene_get_info(self.h, C.byref(i)))
+        return i
+
+    def bvh(self):
+        i = self.info()
+        nodes = np.zeros((i.nnodes, 8), np.uint32)
+        order = np.zeros(max(1, i.ntris), np.uint32)
+        _check(lib().rtx_scene_get_bvh(self.h, nodes.ctypes.data_as(_u), order.ctypes.data_as(_u)))
+        return nodes, order[:i.ntris]
+
+    def trace_closest(self, o, d, full=False):
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        n = len(o)
+        t = np.zeros(n, np.float32)
+        face = np.zeros(n, np.int32)
+        if not full:
+            _check(lib().rtx_trace_closest(self.h, fp(o), fp(d), n, fp(t), face.ctypes.data_as(_i), None, None, None))
+            return t, face
+        nrm = np.zeros((n, 3), np.float32)
+        pt = np.zeros((n, 3), np.float32)
+        mat = np.zeros(n, np.int32)
+        _check(lib().rtx_trace_closest(self.h, fp(o), fp(d), n, fp(t), face.ctypes.data_as(_i), fp(nrm), fp(pt),
+                                       mat.ctypes.data_as(_i)))
+        return t, face, nrm, pt, mat
+
+    def trace_closest_dev(self, o_ptr, d_ptr, n, t_ptr, face_ptr):
+        _check(lib().rtx_trace_closest_dev(self.h, o_ptr, d_ptr, n, t_ptr, face_ptr))
+
+    def trace_visible(self, light, pos):
+        light = np.ascontiguousarray(light, np.float32).reshape(-1, 3)
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+        n = len(pos)
+        vis = np.zeros(n, np.uint8)
+        bm = np.zeros(n, np.int32)
+        _check(lib().rtx_trace_visible(self.h, fp(light), fp(pos), n, vis.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                       bm.ctypes.data_as(_i)))
+        return vis, bm
+
+    def render(self, cam, opts, rect, want_rgb=True, want_hits=True):
+        x0, y0, x1, y1 = rect
+        W, H = x1 - x0, y1 - y0
+        rgb = np.zeros((H, W, 3), np.float32) if want_rgb else None
+        t = np.zeros((H, W), np.float32) if want_hits else None
+        face = np.zeros((H, W), np.int32) if want_hits else None
+        _check(lib().rtx_render(self.h, C.byref(cam), C.byref(opts), Rect(x0, y0, x1, y1),
+                                fp(rgb) if want_rgb else None, fp(t) if want_hits else None,
+                                face.ctypes.data_as(_i) if want_hits else None))
+        return rgb, t, face
+
+    def render_dev(self, cam, opts, rect, rgb_ptr, t_ptr, face_ptr):
+        x0, y0, x1, y1 = rect
+        _check(lib().rtx_render_dev(self.h, C.byref(cam), C.byref(opts), Rect(x0, y0, x1, y1), rgb_ptr, t_ptr,
+                                    face_ptr))
+
+    def stats(self):
+        s = Stats()
+        _check(lib().rtx_get_stats(self.h, C.byref(s)))
+        return s

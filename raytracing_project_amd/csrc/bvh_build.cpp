@@ -1,0 +1,226 @@
+// Binned-SAH builder for the 32-byte-node linear BVH (see bvh_build.h).
+// Replaces Flyscene::divideBox_KD (src/flyscene.cpp:1110-1185), whose tree is never even
+// attached to the root box in the reference; only the *results* of closest-hit
+// queries have to agree with the reference's brute-force scan, which holds for any
+// conservative hierarchy because hits are reduced with a (t, faceId) lexicographic min.
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+namespace rtx {
+namespace {
+
+constexpr int kBins = 16;
+constexpr float kTravCost = 1.2f;
+
+struct Box3 {
+  float lo[3], hi[3];
+  void reset() { for (int k = 0; k < 3; ++k) { lo[k] = FLT_MAX; hi[k] = -FLT_MAX; } }
+  void grow(const float* l, const float* h) {
+    for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], l[k]); hi[k] = std::max(hi[k], h[k]); }
+  }
+  void grow(const Box3& b) { grow(b.lo, b.hi); }
+  float half_area() const {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if (dx < 0 || dy < 0 || dz < 0) return 0.0f;
+    return dx * dy + dy * dz + dz * dx;
+  }
+};
+
+struct Ctx {
+  const float* lo;
+  const float* hi;
+  std::vector<float> cen;   // 3 per triangle
+  uint32_t* ord;
+};
+
+struct Task { uint32_t node, b, e; int depth; };
+
+struct SubtreeBuilder {
+  const Ctx& c;
+  std::vector<BvhNode>& nodes;   // nodes[root] must exist
+  uint32_t nleaves = 0, max_depth = 0;
+  SubtreeBuilder(const Ctx& ctx, std::vector<BvhNode>& n) : c(ctx), nodes(n) {}
+
+  static int levels_needed(uint32_t count) {
+    uint32_t leaves = (count + kMaxLeafTris - 1) / kMaxLeafTris;
+    int l = 0;
+    while ((1u << l) < leaves) ++l;
+    return l;
+  }
+
+  void make_leaf(uint32_t node, uint32_t b, uint32_t e, const Box3& bb, int depth) {
+    BvhNode& n = nodes[node];
+    std::memcpy(n.lo, bb.lo, 12); std::memcpy(n.hi, bb.hi, 12);
+    n.leftFirst = b; n.count = e - b;
+    // keep triangles of a leaf in ascending input-id order (cheap, helps tie handling stay local)
+    std::sort(c.ord + b, c.ord + e);
+    ++nleaves;
+    max_depth = std::max<uint32_t>(max_depth, depth);
+  }
+
+  // Returns the split position (b < mid < e) or 0 when the range should become a leaf.
+  uint32_t split(uint32_t b, uint32_t e, const Box3& bb, const Box3& cb, int depth) {
+    const uint32_t count = e - b;
+    const bool must_balance = depth + levels_needed(count) >= kMaxDepth;
+    int best_axis = -1, best_bin = -1;
+    float best_cost = FLT_MAX;
+    if (!must_balance) {
+      for (int axis = 0; axis < 3; ++axis) {
+        float ext = cb.hi[axis] - cb.lo[axis];
+        if (!(ext > 0.0f)) continue;
+        Box3 bins[kBins]; uint32_t cnt[kBins];
+        for (int i = 0; i < kBins; ++i) { bins[i].reset(); cnt[i] = 0; }
+        const float scale = kBins / ext;
+        for (uint32_t i = b; i < e; ++i) {
+          uint32_t t = c.ord[i];
+          int bi = (int)((c.cen[3 * t + axis] - cb.lo[axis]) * scale);
+          bi = bi < 0 ? 0 : (bi >= kBins ? kBins - 1 : bi);
+          bins[bi].grow(c.lo + 3 * t, c.hi + 3 * t);
+          ++cnt[bi];
+        }
+        float right_area[kBins]; uint32_t right_cnt[kBins];
+        Box3 acc; acc.reset(); uint32_t n = 0;
+        for (int i = kBins - 1; i > 0; --i) { acc.grow(bins[i]); n += cnt[i]; right_area[i] = acc.half_area(); right_cnt[i] = n; }
+        acc.reset(); n = 0;
+        for (int i = 0; i < kBins - 1; ++i) {
+          acc.grow(bins[i]); n += cnt[i];
+          if (n == 0 || right_cnt[i + 1] == 0) continue;
+          float cost = acc.half_area() * n + right_area[i + 1] * right_cnt[i + 1];
+          if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = i; }
+        }
+      }
+    }
+    if (best_axis >= 0) {
+      float parent = bb.half_area();
+      float split_cost = kTravCost + (parent > 0 ? best_cost / parent : FLT_MAX);
+      if (count <= (uint32_t)kMaxLeafTris && split_cost >= (float)count) return 0;
+      float ext = cb.hi[best_axis] - cb.lo[best_axis];
+      const float scale = kBins / ext, lo = cb.lo[best_axis];
+      const int ax = best_axis, bin = best_bin;
+      const Ctx& cc = c;
+      uint32_t* mid = std::partition(c.ord + b, c.ord + e, [&](uint32_t t) {
+        int bi = (int)((cc.cen[3 * t + ax] - lo) * scale);
+        bi = bi < 0 ? 0 : (bi >= kBins ? kBins - 1 : bi);
+        return bi <= bin;
+      });
+      uint32_t m = (uint32_t)(mid - c.ord);
+      if (m > b && m < e) return m;
+    }
+    if (count <= (uint32_t)kMaxLeafTris) return 0;
+    // balanced fallback: median along the widest centroid axis (also the depth guard)
+    int axis = 0;
+    for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
+    uint32_t m = b + count / 2;
+    const Ctx& cc = c;
+    std::nth_element(c.ord + b, c.ord + m, c.ord + e, [&](uint32_t x, uint32_t y) {
+      float cx = cc.cen[3 * x + axis], cy = cc.cen[3 * y + axis];
+      return cx < cy || (cx == cy && x < y);
+    });
+    return m;
+  }
+
+  void bounds(uint32_t b, uint32_t e, Box3* bb, Box3* cb) const {
+    bb->reset(); cb->reset();
+    for (uint32_t i = b; i < e; ++i) {
+      uint32_t t = c.ord[i];
+      bb->grow(c.lo + 3 * t, c.hi + 3 * t);
+      cb->grow(&c.cen[3 * t], &c.cen[3 * t]);
+    }
+  }
+
+  // Expands node `node` over ord[b,e).  When `stop` is non-null, ranges <= stop_size are
+  // not expanded but recorded as tasks (top phase).
+  void build(uint32_t node, uint32_t b, uint32_t e, int depth, std::vector<Task>* stop, uint32_t stop_size) {
+    std::vector<Task> stack;
+    stack.push_back({node, b, e, depth});
+    while (!stack.empty()) {
+      Task t = stack.back(); stack.pop_back();
+      if (stop && t.e - t.b <= stop_size) { stop->push_back(t); continue; }
+      Box3 bb, cb;
+      bounds(t.b, t.e, &bb, &cb);
+      uint32_t mid = split(t.b, t.e, bb, cb, t.depth);
+      if (mid == 0) { make_leaf(t.node, t.b, t.e, bb, t.depth); continue; }
+      uint32_t left = (uint32_t)nodes.size();
+      nodes.emplace_back(); nodes.emplace_back();
+      BvhNode& n = nodes[t.node];
+      std::memcpy(n.lo, bb.lo, 12); std::memcpy(n.hi, bb.hi, 12);
+      n.leftFirst = left; n.count = 0;
+      // right pushed first so the left subtree is laid out right after its parent pair
+      stack.push_back({left + 1, mid, t.e, t.depth + 1});
+      stack.push_back({left, t.b, mid, t.depth + 1});
+    }
+  }
+};
+
+}  // namespace
+
+void build_bvh(const float* tri_lo, const float* tri_hi, uint32_t ntris, int threads, BvhBuildResult* out) {
+  out->nodes.clear(); out->order.clear(); out->nleaves = 0; out->max_depth = 0;
+  out->order.resize(ntris);
+  for (uint32_t i = 0; i < ntris; ++i) out->order[i] = i;
+  out->nodes.reserve((size_t)ntris * 2 + 2);
+  out->nodes.emplace_back();
+  if (ntris == 0) {
+    // Empty mesh: a lone root with an inverted (empty) box.  The traversal kernels never
+    // descend when the scene has no triangles (DevScene::ntris == 0).
+    BvhNode& n = out->nodes[0];
+    for (int k = 0; k < 3; ++k) { n.lo[k] = FLT_MAX; n.hi[k] = -FLT_MAX; }
+    n.leftFirst = 0; n.count = 0;
+    return;
+  }
+  Ctx ctx;
+  ctx.lo = tri_lo; ctx.hi = tri_hi; ctx.ord = out->order.data();
+  ctx.cen.resize((size_t)ntris * 3);
+  for (size_t i = 0; i < (size_t)ntris * 3; ++i) ctx.cen[i] = 0.5f * tri_lo[i] + 0.5f * tri_hi[i];
+
+  if (threads < 1) threads = 1;
+  std::vector<Task> tasks;
+  SubtreeBuilder top(ctx, out->nodes);
+  uint32_t stop_size = 0;
+  if (threads > 1 && ntris > 65536) stop_size = std::max<uint32_t>(ntris / (uint32_t)(threads * 8), 8192);
+  top.build(0, 0, ntris, 0, stop_size ? &tasks : nullptr, stop_size);
+  out->nleaves = top.nleaves; out->max_depth = top.max_depth;
+  if (tasks.empty()) return;
+
+  struct Local { std::vector<BvhNode> nodes; uint32_t nleaves = 0, max_depth = 0; };
+  std::vector<Local> locals(tasks.size());
+  std::atomic<size_t> next{0};
+  auto worker = [&]() {
+    for (;;) {
+      size_t i = next.fetch_add(1);
+      if (i >= tasks.size()) break;
+      Local& L = locals[i];
+      L.nodes.reserve((size_t)(tasks[i].e - tasks[i].b) + 2);
+      L.nodes.emplace_back();
+      SubtreeBuilder sb(ctx, L.nodes);
+      sb.build(0, tasks[i].b, tasks[i].e, tasks[i].depth, nullptr, 0);
+      L.nleaves = sb.nleaves; L.max_depth = sb.max_depth;
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+  for (auto& t : pool) t.join();
+  // stitch in task order: local node 0 -> reserved global slot, local nodes 1.. appended
+  for (size_t i = 0; i < tasks.size(); ++i) {
+    Local& L = locals[i];
+    uint32_t off = (uint32_t)out->nodes.size();
+    auto fix = [&](BvhNode n) { if (n.count == 0) n.leftFirst = off + n.leftFirst - 1; return n; };
+    bool root_internal = L.nodes.size() > 1;
+    out->nodes[tasks[i].node] = root_internal ? fix(L.nodes[0]) : L.nodes[0];
+    for (size_t k = 1; k < L.nodes.size(); ++k) {
+      BvhNode n = L.nodes[k];
+      // a leaf has count > 0 here (ntris > 0), so count == 0 means internal
+      out->nodes.push_back(n.count == 0 ? fix(n) : n);
+    }
+    out->nleaves += L.nleaves;
+    out->max_depth = std::max(out->max_depth, L.max_depth);
+  }
+}
+
+}  // namespace rtx

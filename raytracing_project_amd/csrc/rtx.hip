@@ -1,0 +1,586 @@
+// librtx.so -- C ABI (include/rtx.h) over the HIP kernels in rtx_kernels.h.
+// Host side: scene flattening with the reference's arithmetic, BVH build, uploads,
+// the generation loop of the ray queue, statistics.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/rtx.h"
+#include "bvh_build.h"
+#include "rtx_kernels.h"
+
+using namespace rtx;
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) return fail(RTX_EHIP, "%s: %s", #expr, hipGetErrorString(e_));   \
+  } while (0)
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; return fail(RTX_EHIP, "hipMalloc(%zu): %s", want, hipGetErrorString(e)); }
+    cap = want;
+    return 0;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct EventPool {
+  std::vector<hipEvent_t> ev;
+  size_t used = 0;
+  hipEvent_t get() {
+    if (used == ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; ev.push_back(e); }
+    return ev[used++];
+  }
+  void reset() { used = 0; }
+  void release() { for (auto e : ev) (void)hipEventDestroy(e); ev.clear(); used = 0; }
+};
+
+}  // namespace
+
+struct rtx_scene {
+  // host description
+  std::vector<float> verts;
+  std::vector<uint32_t> idx;
+  std::vector<int32_t> tri_mat;
+  std::vector<rtx_material> mats;
+  std::vector<float> spheres;
+  std::vector<int32_t> sph_mat;
+  std::vector<float> lights, slights;
+  // host-built acceleration data (rtx_scene_build)
+  bool built = false;
+  std::vector<float4> h_tri_leaf, h_face_nm;
+  std::vector<int32_t> h_tri_face;
+  float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
+  // committed state
+  bool committed = false;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  BvhBuildResult bvh;
+  DevScene dev{};
+  DevBuf d_nodes, d_tris, d_tri_face, d_face_nm, d_spheres, d_sph_mat, d_mats, d_lights;
+  // workspace
+  DevBuf w_rays[2], w_hits[2], w_parents, w_shadow_rays, w_shadow_hits, w_counters, w_io[6];
+  EventPool events;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_spans, all_spans;
+  rtx_stats stats{};
+  rtx_scene_info info{};
+  int ncu = 256;
+};
+
+extern "C" const char* rtx_last_error(void) { return g_err.c_str(); }
+
+extern "C" int rtx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int rtx_scene_create(const float* verts, uint32_t nverts, const uint32_t* idx, const int32_t* tri_mat,
+                                uint32_t ntris, const rtx_material* mats, uint32_t nmats, rtx_scene** out) {
+  if (!out) return fail(RTX_EINVAL, "out is null");
+  if ((nverts && !verts) || (ntris && !idx) || (nmats && !mats)) return fail(RTX_EINVAL, "null array with non-zero count");
+  if (ntris >= (1u << 28)) return fail(RTX_ELIMIT, "at most 2^28-1 triangles (got %u)", ntris);
+  for (size_t i = 0; i < (size_t)ntris * 3; ++i)
+    if (idx[i] >= nverts) return fail(RTX_EINVAL, "vertex index %u out of range at position %zu (nverts=%u)", idx[i], i, nverts);
+  rtx_scene* s = new rtx_scene();
+  s->verts.assign(verts, verts + (size_t)nverts * 3);
+  s->idx.assign(idx, idx + (size_t)ntris * 3);
+  if (tri_mat) s->tri_mat.assign(tri_mat, tri_mat + ntris); else s->tri_mat.assign(ntris, -1);
+  s->mats.assign(mats, mats + nmats);
+  *out = s;
+  return RTX_OK;
+}
+
+static void release_device(rtx_scene* s) {
+  if (s->device >= 0) (void)hipSetDevice(s->device);
+  DevBuf* bufs[] = {&s->d_nodes, &s->d_tris, &s->d_tri_face, &s->d_face_nm, &s->d_spheres, &s->d_sph_mat, &s->d_mats,
+                    &s->d_lights, &s->w_rays[0], &s->w_rays[1], &s->w_hits[0], &s->w_hits[1], &s->w_parents,
+                    &s->w_shadow_rays, &s->w_shadow_hits, &s->w_counters, &s->w_io[0], &s->w_io[1], &s->w_io[2],
+                    &s->w_io[3], &s->w_io[4], &s->w_io[5]};
+  for (DevBuf* b : bufs) b->release();
+  s->events.release();
+  if (s->stream) { (void)hipStreamDestroy(s->stream); s->stream = nullptr; }
+  s->committed = false;
+}
+
+extern "C" int rtx_scene_destroy(rtx_scene* s) {
+  if (!s) return RTX_OK;
+  release_device(s);
+  delete s;
+  return RTX_OK;
+}
+
+extern "C" int rtx_scene_add_material(rtx_scene* s, const rtx_material* m) {
+  if (!s || !m) return fail(RTX_EINVAL, "null argument");
+  s->mats.push_back(*m);
+  s->committed = false;
+  return (int)s->mats.size() - 1;
+}
+
+extern "C" int rtx_scene_set_spheres(rtx_scene* s, const float* cr4, const int32_t* mat, uint32_t n) {
+  if (!s || (n && (!cr4 || !mat))) return fail(RTX_EINVAL, "null argument");
+  s->spheres.assign(cr4, cr4 + (size_t)n * 4);
+  s->sph_mat.assign(mat, mat + n);
+  s->committed = false;
+  return RTX_OK;
+}
+
+extern "C" int rtx_scene_set_lights(rtx_scene* s, const float* xyz, uint32_t n, const float* sxyzr, uint32_t m) {
+  if (!s || (n && !xyz) || (m && !sxyzr)) return fail(RTX_EINVAL, "null argument");
+  s->lights.assign(xyz, xyz + (size_t)n * 3);
+  s->slights.assign(sxyzr, sxyzr + (size_t)m * 4);
+  s->committed = false;
+  return RTX_OK;
+}
+
+template <class T>
+static int upload(DevBuf& b, const std::vector<T>& v, hipStream_t st) {
+  size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+  if (int rc = b.ensure(bytes)) return rc;
+  if (!v.empty()) HIP_TRY(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+  return RTX_OK;
+}
+
+extern "C" int rtx_scene_build(rtx_scene* s) {
+  if (!s) return fail(RTX_EINVAL, "null scene");
+  if (s->built) return RTX_OK;
+  auto t0 = std::chrono::steady_clock::now();
+  const uint32_t ntris = (uint32_t)s->tri_mat.size();
+  const uint32_t nverts = (uint32_t)(s->verts.size() / 3);
+  // ---- flatten: per-face constants in the reference's arithmetic (rtx_math.h)
+  std::vector<float4> tri_rec((size_t)ntris * 4);        // mesh order first, permuted below
+  std::vector<float4>& face_nm = s->h_face_nm;
+  face_nm.assign(std::max<uint32_t>(ntris, 1), make_float4(0, 0, 0, 0));
+  std::vector<float> lo((size_t)ntris * 3), hi((size_t)ntris * 3);
+  float scene_abs = 0.0f;
+  for (size_t i = 0; i < s->verts.size(); ++i) scene_abs = std::max(scene_abs, std::fabs(s->verts[i]));
+  const float pad_abs = std::max(2e-5f * scene_abs, 1e-30f);
+  auto vert = [&](uint32_t i) { return v3(s->verts[3 * i], s->verts[3 * i + 1], s->verts[3 * i + 2]); };
+  for (uint32_t f = 0; f < ntris; ++f) {
+    const V3 a = vert(s->idx[3 * f]), b = vert(s->idx[3 * f + 1]), c = vert(s->idx[3 * f + 2]);
+    const V3 nf = face_normal(a, b, c);       // tucano/mesh.hpp:461-463
+    const V3 nq = normalized(nf);             // src/flyscene.cpp:839 (identity model matrix)
+    const V3 u = b - a, v = c - a;            // src/Intersect.cpp:26-27
+    const float D = dot(nq, a);               // src/Intersect.cpp:10
+    const float uu = dot(u, u), uv = dot(u, v), vv = dot(v, v);
+    tri_rec[4 * (size_t)f + 0] = make_float4(a.x, a.y, a.z, D);
+    tri_rec[4 * (size_t)f + 1] = make_float4(u.x, u.y, u.z, uu);
+    tri_rec[4 * (size_t)f + 2] = make_float4(v.x, v.y, v.z, uv);
+    tri_rec[4 * (size_t)f + 3] = make_float4(nq.x, nq.y, nq.z, vv);
+    int32_t m = s->tri_mat[f];
+    float mw; std::memcpy(&mw, &m, 4);
+    face_nm[f] = make_float4(nq.x, nq.y, nq.z, mw);
+    // padded culling box: the reference accepts hit points a little outside the exact
+    // triangle (fp32 barycentrics, worse for slivers), so boxes get an absolute and a
+    // size-relative margin; see DESIGN.md "conservative boxes".
+    const float pa[3] = {a.x, a.y, a.z}, pb[3] = {b.x, b.y, b.z}, pc[3] = {c.x, c.y, c.z};
+    float ext = 0.0f;
+    for (int k = 0; k < 3; ++k) {
+      float mn = std::min(pa[k], std::min(pb[k], pc[k])), mx = std::max(pa[k], std::max(pb[k], pc[k]));
+      lo[3 * (size_t)f + k] = mn; hi[3 * (size_t)f + k] = mx;
+      ext = std::max(ext, mx - mn);
+    }
+    const float pad = pad_abs + 2e-3f * ext;
+    for (int k = 0; k < 3; ++k) { lo[3 * (size_t)f + k] -= pad; hi[3 * (size_t)f + k] += pad; }
+  }
+  // ---- BVH
+  int threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+  build_bvh(lo.data(), hi.data(), ntris, threads, &s->bvh);
+  std::vector<float4>& tri_leaf = s->h_tri_leaf;
+  std::vector<int32_t>& tri_face = s->h_tri_face;
+  tri_leaf.assign((size_t)ntris * 4, make_float4(0, 0, 0, 0));
+  tri_face.assign(std::max<uint32_t>(ntris, 1), 0);
+  for (uint32_t k = 0; k < ntris; ++k) {
+    uint32_t f = s->bvh.order[k];
+    tri_face[k] = (int32_t)f;
+    std::memcpy(&tri_leaf[4 * (size_t)k], &tri_rec[4 * (size_t)f], 64);
+  }
+  // Box(Tucano::Mesh) (src/box.h:41-85): max seeded with numeric_limits<float>::min()
+  float mx[3] = {1.17549435e-38f, 1.17549435e-38f, 1.17549435e-38f};
+  float mn[3] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f};
+  for (uint32_t i = 0; i < nverts; ++i)
+    for (int k = 0; k < 3; ++k) {
+      float x = s->verts[3 * (size_t)i + k];
+      if (x > mx[k]) mx[k] = x;
+      if (x < mn[k]) mn[k] = x;
+    }
+  for (int k = 0; k < 3; ++k) { s->root_lo[k] = mn[k]; s->root_hi[k] = mx[k]; }
+  auto t1 = std::chrono::steady_clock::now();
+  rtx_scene_info& in = s->info;
+  std::memset(&in, 0, sizeof in);
+  in.ntris = ntris; in.nverts = nverts; in.nnodes = (uint32_t)s->bvh.nodes.size(); in.nleaves = s->bvh.nleaves;
+  in.max_depth = s->bvh.max_depth;
+  in.build_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+  if (s->bvh.max_depth + 2 > (uint32_t)kStackDepth) return fail(RTX_ELIMIT, "BVH depth %u exceeds the traversal stack", s->bvh.max_depth);
+  s->built = true;
+  return RTX_OK;
+}
+
+extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
+  if (!s) return fail(RTX_EINVAL, "null scene");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(RTX_EINVAL, "device %d out of range (%d devices)", device, ndev);
+  if (s->device >= 0 && s->device != device) release_device(s);
+  HIP_TRY(hipSetDevice(device));
+  s->device = device;
+  if (!s->stream) HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  s->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (int rc = rtx_scene_build(s)) return rc;
+  const uint32_t ntris = (uint32_t)s->tri_mat.size();
+  const std::vector<float4>& tri_leaf = s->h_tri_leaf;
+  const std::vector<int32_t>& tri_face = s->h_tri_face;
+  const std::vector<float4>& face_nm = s->h_face_nm;
+  // ---- upload
+  std::vector<DevMat> dm(std::max<size_t>(s->mats.size(), 1));
+  for (size_t i = 0; i < s->mats.size(); ++i) {
+    const rtx_material& m = s->mats[i];
+    DevMat& d = dm[i];
+    std::memset(&d, 0, sizeof d);
+    for (int k = 0; k < 3; ++k) { d.ka[k] = m.ka[k]; d.kd[k] = m.kd[k]; d.ks[k] = m.ks[k]; }
+    d.ns = m.ns; d.ni = m.ni; d.d = m.d; d.illum = m.illum;
+  }
+  std::vector<float4> dl(std::max<size_t>(s->lights.size() / 3, 1));
+  for (size_t i = 0; i < s->lights.size() / 3; ++i) dl[i] = make_float4(s->lights[3 * i], s->lights[3 * i + 1], s->lights[3 * i + 2], 0.0f);
+  std::vector<float4> ds(std::max<size_t>(s->spheres.size() / 4, 1));
+  for (size_t i = 0; i < s->spheres.size() / 4; ++i) ds[i] = make_float4(s->spheres[4 * i], s->spheres[4 * i + 1], s->spheres[4 * i + 2], s->spheres[4 * i + 3]);
+  std::vector<int32_t> dsm = s->sph_mat; if (dsm.empty()) dsm.push_back(-1);
+  if (int rc = upload(s->d_nodes, s->bvh.nodes, s->stream)) return rc;
+  if (int rc = upload(s->d_tris, tri_leaf, s->stream)) return rc;
+  if (int rc = upload(s->d_tri_face, tri_face, s->stream)) return rc;
+  if (int rc = upload(s->d_face_nm, face_nm, s->stream)) return rc;
+  if (int rc = upload(s->d_spheres, ds, s->stream)) return rc;
+  if (int rc = upload(s->d_sph_mat, dsm, s->stream)) return rc;
+  if (int rc = upload(s->d_mats, dm, s->stream)) return rc;
+  if (int rc = upload(s->d_lights, dl, s->stream)) return rc;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+
+  DevScene& d = s->dev;
+  d.nodes = s->d_nodes.as<float4>(); d.tris = s->d_tris.as<float4>(); d.tri_face = s->d_tri_face.as<int>();
+  d.face_nm = s->d_face_nm.as<float4>(); d.spheres = s->d_spheres.as<float4>(); d.sph_mat = s->d_sph_mat.as<int>();
+  d.mats = s->d_mats.as<DevMat>(); d.lights = s->d_lights.as<float4>();
+  d.ntris = ntris; d.nspheres = (uint32_t)(s->spheres.size() / 4); d.nlights = (uint32_t)(s->lights.size() / 3);
+  d.nmats = (uint32_t)s->mats.size();
+  for (int k = 0; k < 3; ++k) { d.root_lo[k] = s->root_lo[k]; d.root_hi[k] = s->root_hi[k]; }
+  const BvhNode& root = s->bvh.nodes[0];
+  d.root_entry = root.count ? (kLeafBit | (root.count << 28) | root.leftFirst) : root.leftFirst;
+  rtx_scene_info& in = s->info;
+  in.nspheres = d.nspheres; in.nlights = d.nlights; in.nmaterials = d.nmats;
+  in.device_bytes = s->d_nodes.cap + s->d_tris.cap + s->d_tri_face.cap + s->d_face_nm.cap + s->d_spheres.cap +
+                    s->d_sph_mat.cap + s->d_mats.cap + s->d_lights.cap;
+  s->committed = true;
+  return RTX_OK;
+}
+
+extern "C" int rtx_scene_get_info(const rtx_scene* s, rtx_scene_info* out) {
+  if (!s || !out) return fail(RTX_EINVAL, "null argument");
+  if (!s->built) return fail(RTX_ESTATE, "scene not built (rtx_scene_build / rtx_scene_commit)");
+  *out = s->info;
+  return RTX_OK;
+}
+
+extern "C" int rtx_scene_get_tris(const rtx_scene* s, float* tri16) {
+  if (!s || !tri16) return fail(RTX_EINVAL, "null argument");
+  if (!s->built) return fail(RTX_ESTATE, "scene not built (rtx_scene_build / rtx_scene_commit)");
+  std::memcpy(tri16, s->h_tri_leaf.data(), s->h_tri_leaf.size() * sizeof(float4));
+  return RTX_OK;
+}
+
+extern "C" int rtx_scene_get_bvh(const rtx_scene* s, uint32_t* nodes8, uint32_t* tri_face) {
+  if (!s) return fail(RTX_EINVAL, "null scene");
+  if (!s->built) return fail(RTX_ESTATE, "scene not built (rtx_scene_build / rtx_scene_commit)");
+  if (nodes8) std::memcpy(nodes8, s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(BvhNode));
+  if (tri_face) std::memcpy(tri_face, s->bvh.order.data(), s->bvh.order.size() * 4);
+  return RTX_OK;
+}
+
+// ------------------------------------------------------------------ launch helpers
+static int grid_for(const rtx_scene* s, size_t items) {
+  size_t blocks = (items + kBlock - 1) / kBlock;
+  size_t cap = (size_t)s->ncu * 8;
+  return (int)std::max<size_t>(1, std::min(blocks, cap));
+}
+static void span_begin(rtx_scene* s, bool trace) {
+  hipEvent_t a = s->events.get(), b = s->events.get();
+  (void)hipEventRecord(a, s->stream);
+  (trace ? s->trace_spans : s->all_spans).push_back({a, b});
+}
+static void span_end(rtx_scene* s, bool trace) {
+  (void)hipEventRecord((trace ? s->trace_spans : s->all_spans).back().second, s->stream);
+}
+static void stats_begin(rtx_scene* s) {
+  s->events.reset(); s->trace_spans.clear(); s->all_spans.clear();
+  std::memset(&s->stats, 0, sizeof s->stats);
+  span_begin(s, false);
+}
+static int stats_end(rtx_scene* s) {
+  span_end(s, false);
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipGetLastError());
+  float ms = 0;
+  for (auto& sp : s->trace_spans) { float m = 0; (void)hipEventElapsedTime(&m, sp.first, sp.second); ms += m; }
+  s->stats.ms_trace = ms;
+  s->stats.launches_trace = (uint32_t)s->trace_spans.size();
+  float tot = 0;
+  (void)hipEventElapsedTime(&tot, s->all_spans[0].first, s->all_spans[0].second);
+  s->stats.ms_total = tot;
+  return RTX_OK;
+}
+static int check_ready(rtx_scene* s) {
+  if (!s) return fail(RTX_EINVAL, "null scene");
+  if (!s->committed) return fail(RTX_ESTATE, "scene not committed (call rtx_scene_commit after any change)");
+  HIP_TRY(hipSetDevice(s->device));
+  return RTX_OK;
+}
+
+// Traces `n` caller rays held on the device (xyz arrays) into w_hits[0]; w_rays[0] keeps the records.
+static int trace_rays_dev(rtx_scene* s, const float* d_o, const float* d_d, uint32_t n) {
+  if (int rc = s->w_rays[0].ensure((size_t)n * 32)) return rc;
+  if (int rc = s->w_hits[0].ensure((size_t)n * 8)) return rc;
+  if (int rc = s->w_counters.ensure(64)) return rc;
+  HIP_TRY(hipMemcpyAsync(s->w_counters.p, &n, 4, hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(k_make_rays, dim3((n + 255) / 256), dim3(256), 0, s->stream, d_o, d_d, n, s->w_rays[0].as<float4>());
+  span_begin(s, true);
+  hipLaunchKernelGGL(k_trace_queue, dim3(grid_for(s, n)), dim3(kBlock), 0, s->stream, s->dev, s->w_rays[0].as<float4>(),
+                     s->w_counters.as<uint32_t>(), 1u, s->w_hits[0].as<uint2>());
+  span_end(s, true);
+  return RTX_OK;
+}
+
+extern "C" int rtx_trace_closest_dev(rtx_scene* s, const float* o, const float* d, uint32_t n, float* t, int32_t* face) {
+  if (int rc = check_ready(s)) return rc;
+  if (n == 0) return RTX_OK;
+  if (!o || !d) return fail(RTX_EINVAL, "null ray arrays");
+  stats_begin(s);
+  if (int rc = trace_rays_dev(s, o, d, n)) return rc;
+  hipLaunchKernelGGL(k_unpack_hits, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->dev, s->w_rays[0].as<float4>(),
+                     s->w_hits[0].as<uint2>(), n, t, face, (float*)nullptr, (float*)nullptr, (int*)nullptr);
+  s->stats.rays_primary = n;
+  return stats_end(s);
+}
+
+extern "C" int rtx_trace_closest(rtx_scene* s, const float* o, const float* d, uint32_t n, float* t, int32_t* face,
+                                 float* normal, float* point, int32_t* mat) {
+  if (int rc = check_ready(s)) return rc;
+  if (n == 0) return RTX_OK;
+  if (!o || !d) return fail(RTX_EINVAL, "null ray arrays");
+  const size_t b3 = (size_t)n * 12, b1 = (size_t)n * 4;
+  if (int rc = s->w_io[0].ensure(b3)) return rc;
+  if (int rc = s->w_io[1].ensure(b3)) return rc;
+  if (int rc = s->w_io[2].ensure(b1)) return rc;
+  if (int rc = s->w_io[3].ensure(b1)) return rc;
+  if (int rc = s->w_io[4].ensure(b3 * 2)) return rc;
+  if (int rc = s->w_io[5].ensure(b1)) return rc;
+  HIP_TRY(hipMemcpyAsync(s->w_io[0].p, o, b3, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->w_io[1].p, d, b3, hipMemcpyHostToDevice, s->stream));
+  stats_begin(s);
+  if (int rc = trace_rays_dev(s, s->w_io[0].as<float>(), s->w_io[1].as<float>(), n)) return rc;
+  float* d_n = s->w_io[4].as<float>();
+  float* d_p = d_n + (size_t)n * 3;
+  hipLaunchKernelGGL(k_unpack_hits, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->dev, s->w_rays[0].as<float4>(),
+                     s->w_hits[0].as<uint2>(), n, s->w_io[2].as<float>(), s->w_io[3].as<int>(), d_n, d_p, s->w_io[5].as<int>());
+  s->stats.rays_primary = n;
+  if (int rc = stats_end(s)) return rc;
+  if (t) HIP_TRY(hipMemcpy(t, s->w_io[2].p, b1, hipMemcpyDeviceToHost));
+  if (face) HIP_TRY(hipMemcpy(face, s->w_io[3].p, b1, hipMemcpyDeviceToHost));
+  if (normal) HIP_TRY(hipMemcpy(normal, d_n, b3, hipMemcpyDeviceToHost));
+  if (point) HIP_TRY(hipMemcpy(point, d_p, b3, hipMemcpyDeviceToHost));
+  if (mat) HIP_TRY(hipMemcpy(mat, s->w_io[5].p, b1, hipMemcpyDeviceToHost));
+  return RTX_OK;
+}
+
+extern "C" int rtx_trace_visible(rtx_scene* s, const float* light, const float* pos, uint32_t n, uint8_t* visible,
+                                 int32_t* bmat) {
+  if (int rc = check_ready(s)) return rc;
+  if (n == 0) return RTX_OK;
+  if (!light || !pos || !visible) return fail(RTX_EINVAL, "null argument");
+  const size_t b3 = (size_t)n * 12;
+  if (int rc = s->w_io[0].ensure(b3)) return rc;
+  if (int rc = s->w_io[1].ensure(b3)) return rc;
+  if (int rc = s->w_io[2].ensure(n)) return rc;
+  if (int rc = s->w_io[3].ensure((size_t)n * 4)) return rc;
+  if (int rc = s->w_rays[0].ensure((size_t)n * 32)) return rc;
+  if (int rc = s->w_hits[0].ensure((size_t)n * 8)) return rc;
+  if (int rc = s->w_counters.ensure(64)) return rc;
+  HIP_TRY(hipMemcpyAsync(s->w_io[0].p, light, b3, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->w_io[1].p, pos, b3, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->w_counters.p, &n, 4, hipMemcpyHostToDevice, s->stream));
+  stats_begin(s);
+  hipLaunchKernelGGL(k_make_shadow_rays, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->w_io[0].as<float>(),
+                     s->w_io[1].as<float>(), n, s->w_rays[0].as<float4>());
+  span_begin(s, true);
+  hipLaunchKernelGGL(k_trace_queue, dim3(grid_for(s, n)), dim3(kBlock), 0, s->stream, s->dev, s->w_rays[0].as<float4>(),
+                     s->w_counters.as<uint32_t>(), 1u, s->w_hits[0].as<uint2>());
+  span_end(s, true);
+  hipLaunchKernelGGL(k_visible, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->dev, s->w_io[0].as<float>(),
+                     s->w_rays[0].as<float4>(), s->w_hits[0].as<uint2>(), n, s->w_io[2].as<unsigned char>(), s->w_io[3].as<int>());
+  s->stats.rays_shadow = n;
+  if (int rc = stats_end(s)) return rc;
+  HIP_TRY(hipMemcpy(visible, s->w_io[2].p, n, hipMemcpyDeviceToHost));
+  if (bmat) HIP_TRY(hipMemcpy(bmat, s->w_io[3].p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  return RTX_OK;
+}
+
+// ------------------------------------------------------------------ render
+static int make_camera(const rtx_camera* cam, rtx_rect r, DevCamera* C) {
+  if (r.x1 <= r.x0 || r.y1 <= r.y0) return fail(RTX_EINVAL, "empty rectangle");
+  if (!(cam->viewport[2] > 0) || !(cam->viewport[3] > 0)) return fail(RTX_EINVAL, "viewport must have positive size");
+  if ((int64_t)(r.x1 - r.x0) * (int64_t)(r.y1 - r.y0) >= (1ll << 31)) return fail(RTX_ELIMIT, "rectangle has too many pixels");
+  // Transform::inverse (Eigen/src/Geometry/Transform.h:1202-1229) and Camera::getCenter (tucano/camera.hpp:115-118)
+  float lin[9], inv[9], ninv[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) lin[3 * i + j] = cam->view[4 * i + j];
+  mat3_inverse(lin, inv);
+  for (int k = 0; k < 9; ++k) ninv[k] = -inv[k];
+  const V3 tr = v3(cam->view[3], cam->view[7], cam->view[11]);
+  const V3 it = mat3_mul(ninv, tr);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) C->inv34[4 * i + j] = inv[3 * i + j];
+  C->inv34[3] = it.x; C->inv34[7] = it.y; C->inv34[11] = it.z;
+  const V3 ctr = mat3_mul(inv, -tr);
+  C->origin[0] = ctr.x; C->origin[1] = ctr.y; C->origin[2] = ctr.z;
+  for (int k = 0; k < 4; ++k) C->vp[k] = cam->viewport[k];
+  // getPerspectiveScale (tucano/camera.hpp:263-266) and `float scale = 1.0/...` (:165)
+  const float pscale = (float)((double)1.0f / std::tan((double)(cam->fovy / 2.0f) * (M_PI / (double)180.0f)));
+  const float scale = (float)(1.0 / (double)pscale);
+  C->aspect_scale = cam->aspect * scale;
+  C->scale = scale;
+  C->sub[0] = cam->subpixel[0]; C->sub[1] = cam->subpixel[1];
+  C->x0 = r.x0; C->y0 = r.y0; C->w = r.x1 - r.x0; C->h = r.y1 - r.y0;
+  return RTX_OK;
+}
+
+extern "C" int rtx_render_dev(rtx_scene* s, const rtx_camera* cam, const rtx_options* opt, rtx_rect rect, float* rgb,
+                              float* t, int32_t* face) {
+  if (int rc = check_ready(s)) return rc;
+  if (!cam || !opt) return fail(RTX_EINVAL, "null camera/options");
+  if (opt->refraction || opt->gi_rays) return fail(RTX_EINVAL, "refraction / gi_rays are not implemented on the GPU path yet");
+  if (opt->max_bounces < 0 || opt->max_bounces > 16) return fail(RTX_ELIMIT, "max_bounces must be in [0,16]");
+  if (!s->slights.empty() && rgb) return fail(RTX_EINVAL, "spherical lights are not implemented on the GPU path yet");
+  if (rgb && s->dev.nlights == 0) return fail(RTX_EINVAL, "shading needs at least one light (the reference divides by the light count)");
+  DevCamera C;
+  if (int rc = make_camera(cam, rect, &C)) return rc;
+  const uint32_t npix = (uint32_t)C.w * (uint32_t)C.h;
+  const uint32_t NL = s->dev.nlights;
+  const bool shade = rgb != nullptr;
+  if (int rc = s->w_hits[0].ensure((size_t)npix * 8)) return rc;
+  if (int rc = s->w_counters.ensure(4 * 64)) return rc;
+  if (shade) {
+    if (int rc = s->w_parents.ensure((size_t)npix * 4)) return rc;
+    if (opt->shadows) {
+      if (int rc = s->w_shadow_rays.ensure((size_t)npix * NL * 32)) return rc;
+      if (int rc = s->w_shadow_hits.ensure((size_t)npix * NL * 8)) return rc;
+    }
+    if (opt->reflection && opt->max_bounces > 0) {
+      if (int rc = s->w_rays[0].ensure((size_t)npix * 32)) return rc;
+      if (int rc = s->w_rays[1].ensure((size_t)npix * 32)) return rc;
+      if (int rc = s->w_hits[1].ensure((size_t)npix * 8)) return rc;
+    }
+  }
+  stats_begin(s);
+  // counters: per generation g, slots [4g] = #parents, [4g+1] = #rays of generation g+1
+  const int max_gen = shade && opt->reflection ? opt->max_bounces : 0;
+  if (int rc = s->w_counters.ensure((size_t)(max_gen + 2) * 16)) return rc;
+  HIP_TRY(hipMemsetAsync(s->w_counters.p, 0, (size_t)(max_gen + 2) * 16, s->stream));
+  uint32_t* cnt = s->w_counters.as<uint32_t>();
+
+  const uint32_t tiles = (uint32_t)((C.w + 15) / 16) * (uint32_t)((C.h + 15) / 16);
+  span_begin(s, true);
+  hipLaunchKernelGGL(k_trace_camera, dim3(std::min<uint32_t>(tiles, (uint32_t)s->ncu * 64)), dim3(kBlock), 0, s->stream, s->dev, C,
+                     tiles, s->w_hits[0].as<uint2>());
+  span_end(s, true);
+
+  for (int g = 0; g <= max_gen; ++g) {
+    const int cur = g & 1, nxt = cur ^ 1;
+    ShadeArgs A;
+    A.S = s->dev; A.C = C; A.gen = g; A.max_bounces = opt->max_bounces; A.reflection = opt->reflection;
+    A.shadows = opt->shadows; A.skip_zero_weight = opt->skip_zero_weight; A.npix = npix;
+    // generation g > 0 rays live in w_rays[cur]; their count is counters[4(g-1)+1]
+    A.rays = g == 0 ? nullptr : s->w_rays[cur].as<float4>();
+    A.nrays = g == 0 ? nullptr : cnt + 4 * (g - 1) + 1;
+    A.hits = (g == 0 ? s->w_hits[0] : s->w_hits[1]).as<uint2>();
+    A.rgb = rgb; A.out_t = t; A.out_face = face;
+    A.parents = s->w_parents.as<uint32_t>();
+    A.shadow_rays = s->w_shadow_rays.as<float4>();
+    A.next_rays = s->w_rays[nxt].as<float4>();
+    A.counters = cnt + 4 * g;
+    hipLaunchKernelGGL(k_shade, dim3(grid_for(s, npix)), dim3(kBlock), 0, s->stream, A);
+    if (!shade) break;
+    if (opt->shadows) {
+      span_begin(s, true);
+      hipLaunchKernelGGL(k_trace_queue, dim3(grid_for(s, (size_t)npix * NL)), dim3(kBlock), 0, s->stream, s->dev,
+                         s->w_shadow_rays.as<float4>(), cnt + 4 * g, NL, s->w_shadow_hits.as<uint2>());
+      span_end(s, true);
+    }
+    ResolveArgs R;
+    R.S = s->dev; R.C = C; R.gen = g; R.shadows = opt->shadows; R.npix = npix;
+    R.rays = A.rays; R.hits = A.hits; R.parents = A.parents; R.nparents = cnt + 4 * g;
+    R.shadow_rays = A.shadow_rays; R.shadow_hits = s->w_shadow_hits.as<uint2>(); R.rgb = rgb;
+    hipLaunchKernelGGL(k_resolve, dim3(grid_for(s, npix)), dim3(kBlock), 0, s->stream, R);
+    if (g < max_gen) {
+      span_begin(s, true);
+      hipLaunchKernelGGL(k_trace_queue, dim3(grid_for(s, npix)), dim3(kBlock), 0, s->stream, s->dev, s->w_rays[nxt].as<float4>(),
+                         cnt + 4 * g + 1, 1u, s->w_hits[1].as<uint2>());
+      span_end(s, true);
+    }
+  }
+  std::vector<uint32_t> hc((size_t)(max_gen + 2) * 4);
+  HIP_TRY(hipMemcpyAsync(hc.data(), s->w_counters.p, hc.size() * 4, hipMemcpyDeviceToHost, s->stream));
+  if (int rc = stats_end(s)) return rc;
+  s->stats.rays_primary = npix;
+  if (shade) {
+    for (int g = 0; g <= max_gen; ++g) {
+      if (opt->shadows) s->stats.rays_shadow += (uint64_t)hc[4 * g] * NL;
+      if (g < max_gen) s->stats.rays_reflection += hc[4 * g + 1];
+    }
+  }
+  return RTX_OK;
+}
+
+extern "C" int rtx_render(rtx_scene* s, const rtx_camera* cam, const rtx_options* opt, rtx_rect rect, float* rgb, float* t,
+                          int32_t* face) {
+  if (int rc = check_ready(s)) return rc;
+  if (rect.x1 <= rect.x0 || rect.y1 <= rect.y0) return fail(RTX_EINVAL, "empty rectangle");
+  const size_t npix = (size_t)(rect.x1 - rect.x0) * (size_t)(rect.y1 - rect.y0);
+  if (rgb) if (int rc = s->w_io[0].ensure(npix * 12)) return rc;
+  if (t) if (int rc = s->w_io[1].ensure(npix * 4)) return rc;
+  if (face) if (int rc = s->w_io[2].ensure(npix * 4)) return rc;
+  int rc = rtx_render_dev(s, cam, opt, rect, rgb ? s->w_io[0].as<float>() : nullptr, t ? s->w_io[1].as<float>() : nullptr,
+                          face ? s->w_io[2].as<int32_t>() : nullptr);
+  if (rc) return rc;
+  if (rgb) HIP_TRY(hipMemcpy(rgb, s->w_io[0].p, npix * 12, hipMemcpyDeviceToHost));
+  if (t) HIP_TRY(hipMemcpy(t, s->w_io[1].p, npix * 4, hipMemcpyDeviceToHost));
+  if (face) HIP_TRY(hipMemcpy(face, s->w_io[2].p, npix * 4, hipMemcpyDeviceToHost));
+  return RTX_OK;
+}
+
+extern "C" int rtx_get_stats(const rtx_scene* s, rtx_stats* out) {
+  if (!s || !out) return fail(RTX_EINVAL, "null argument");
+  *out = s->stats;
+  return RTX_OK;
+}

@@ -1,0 +1,533 @@
+// HIP kernels of librtx (gfx950 / CDNA4, wave64).  Included only by rtx.hip.
+//
+// Arithmetic contract: everything that decides a hit (ray normalisation, the plane +
+// barycentric triangle test, the sphere quadratic, the root-box gate, t >= 0.001f, strict-<
+// reduction with the lowest face id on ties) is the reference's fp32 arithmetic in the
+// reference's order (src/Intersect.cpp, src/flyscene.cpp:517-585,819-879), compiled with
+// -ffp-contract=off.  The BVH only *skips* triangles whose padded boxes the ray misses.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rtx_math.h"
+
+namespace rtx {
+
+constexpr int kBlock = 256;          // 4 waves of 64
+constexpr int kStackDepth = 32;      // per-lane traversal stack entries, held in LDS
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr float kPrecision = 0.001f; // Intersect::Face::precision (src/Intersect.h:14)
+constexpr float kPruneSlack = 1.0001f;
+
+struct DevMat { float ka[3], kd[3], ks[3]; float ns, ni, d; int illum; int pad[3]; };
+static_assert(sizeof(DevMat) == 64, "material record is 64 bytes");
+
+struct DevScene {
+  const float4* nodes;     // 2 x float4 per node: {lo.xyz, leftFirst}, {hi.xyz, count}
+  const float4* tris;      // 4 x float4 per leaf-ordered triangle: {v0,D} {u,uu} {v,uv} {n,vv}
+  const int* tri_face;     // leaf order -> mesh face id
+  const float4* face_nm;   // per mesh face: {query normal xyz, material id bits}
+  const float4* spheres;   // {center xyz, radius}
+  const int* sph_mat;
+  const DevMat* mats;
+  const float4* lights;    // point lights {xyz, 0}
+  uint32_t ntris, nspheres, nlights, nmats;
+  float root_lo[3], root_hi[3];   // Box(mesh) of the reference, used as its root gate
+  uint32_t root_entry;            // traversal entry of the BVH root
+  uint32_t pad;
+};
+
+struct DevCamera {
+  float inv34[12];     // inverse view, row-major 3x4
+  float origin[3];     // Camera::getCenter
+  float vp[4];
+  float aspect_scale;  // aspect_ratio * scale
+  float scale;         // 1 / getPerspectiveScale
+  float sub[2];
+  int x0, y0, w, h;    // pixel rectangle
+};
+
+struct Hit { float t; int id; };   // id >= 0 mesh face, -1 miss, <= -2 sphere (-2 - index)
+
+// ---------------------------------------------------------------- reference primitives
+// Intersect::BoxObject::intersects (src/Intersect.cpp:67-145); used only for the root gate.
+__device__ __forceinline__ float ref_box_t(V3 o, V3 dir, const float* bmin, const float* bmax) {
+  float ix = 1 / dir.x, iy = 1 / dir.y, iz = 1 / dir.z;
+  float txmin, txmax, tymin, tymax, tzmin, tzmax;
+  if (ix >= 0) { txmin = (bmin[0] - o.x) * ix; txmax = (bmax[0] - o.x) * ix; }
+  else { txmin = (bmax[0] - o.x) * ix; txmax = (bmin[0] - o.x) * ix; }
+  if (iy >= 0) { tymin = (bmin[1] - o.y) * iy; tymax = (bmax[1] - o.y) * iy; }
+  else { tymin = (bmax[1] - o.y) * iy; tymax = (bmin[1] - o.y) * iy; }
+  if ((txmin > tymax) || (tymin > txmax)) return INFINITY;
+  if (tymin > txmin) txmin = tymin;
+  if (tymax < txmax) txmax = tymax;
+  if (iz >= 0) { tzmin = (bmin[2] - o.z) * iz; tzmax = (bmax[2] - o.z) * iz; }
+  else { tzmin = (bmax[2] - o.z) * iz; tzmax = (bmin[2] - o.z) * iz; }
+  if ((txmin > tzmax) || (tzmin > txmax)) return INFINITY;
+  if (tzmin > txmin) txmin = tzmin;
+  if (tzmax < txmax) txmax = tzmax;
+  return txmin;
+}
+
+// Intersect::Sphere::intersects + solveQuadratic (src/Intersect.cpp:147-193): t or INFINITY.
+__device__ __forceinline__ float ref_sphere_t(V3 o, V3 d, float4 s) {
+  float radius2 = s.w * s.w;
+  V3 L = o - v3(s.x, s.y, s.z);
+  float a = dot(d, d);
+  float b = 2.0f * dot(d, L);
+  float c = dot(L, L) - radius2;
+  float discr = b * b - 4.0f * a * c;
+  if (discr < 0) return INFINITY;
+  float x0, x1;
+  if (discr == 0) { x0 = x1 = (float)(-0.5 * (double)b / (double)a); }
+  else {
+    float sq = sqrtf(discr);
+    float q = (b > 0) ? -0.5f * (b + sq) : -0.5f * (b - sq);
+    x0 = q / a;
+    x1 = c / q;
+  }
+  if (x0 > x1) { float tmp = x0; x0 = x1; x1 = tmp; }
+  if (x0 < 0) x0 = x1;
+  if (x0 > 0 && x0 >= kPrecision) return x0;
+  return INFINITY;
+}
+
+__device__ __forceinline__ float cull_inv(float d) {
+  const float iv = 1.0f / d;
+  return (fabsf(iv) <= 1e18f) ? iv : copysignf(1e18f, d);
+}
+
+// ---------------------------------------------------------------- closest hit
+// Flyscene::getIntersections (src/flyscene.cpp:517-585) for the ray Ray(o, .) whose stored
+// direction is d1.  `stk` points at this lane's column of the LDS stack (stride kBlock).
+__device__ __forceinline__ Hit closest_hit(const DevScene& S, V3 o, V3 d1, uint32_t* stk) {
+  Hit best; best.t = INFINITY; best.id = -1;
+  // spheres first, strict < (src/flyscene.cpp:523-532)
+  for (uint32_t i = 0; i < S.nspheres; ++i) {
+    float t = ref_sphere_t(o, d1, S.spheres[i]);
+    if (t != INFINITY && t < best.t) { best.t = t; best.id = -2 - (int)i; }
+  }
+  if (S.ntris == 0) return best;
+  // intersectBox / intersectTriangle rebuild the Ray, re-normalising d1 (src/flyscene.cpp:845,965)
+  const V3 d = normalized(d1);
+  if (!(ref_box_t(o, d, S.root_lo, S.root_hi) != INFINITY)) return best;
+
+  // slab constants for the padded BVH boxes (culling only; not part of the parity contract)
+  // |1/d| is clamped so that an axis-parallel ray gives huge finite slab distances of the
+  // right sign instead of inf - inf = NaN in the fused form below.
+  const float ivx = cull_inv(d.x), ivy = cull_inv(d.y), ivz = cull_inv(d.z);
+  const float oix = o.x * ivx, oiy = o.y * ivy, oiz = o.z * ivz;
+
+  uint32_t cur = S.root_entry;
+  int sp = 0;
+  for (;;) {
+    if (!(cur & kLeafBit)) {
+      const float4 a0 = S.nodes[2 * cur], b0 = S.nodes[2 * cur + 1];
+      const float4 a1 = S.nodes[2 * cur + 2], b1 = S.nodes[2 * cur + 3];
+      const float lim = best.t * kPruneSlack;
+      float tn0, tf0, tn1, tf1;
+      {
+        float x0 = __builtin_fmaf(a0.x, ivx, -oix), x1 = __builtin_fmaf(b0.x, ivx, -oix);
+        float y0 = __builtin_fmaf(a0.y, ivy, -oiy), y1 = __builtin_fmaf(b0.y, ivy, -oiy);
+        float z0 = __builtin_fmaf(a0.z, ivz, -oiz), z1 = __builtin_fmaf(b0.z, ivz, -oiz);
+        tn0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+        tf0 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+      }
+      {
+        float x0 = __builtin_fmaf(a1.x, ivx, -oix), x1 = __builtin_fmaf(b1.x, ivx, -oix);
+        float y0 = __builtin_fmaf(a1.y, ivy, -oiy), y1 = __builtin_fmaf(b1.y, ivy, -oiy);
+        float z0 = __builtin_fmaf(a1.z, ivz, -oiz), z1 = __builtin_fmaf(b1.z, ivz, -oiz);
+        tn1 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+        tf1 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+      }
+      const bool h0 = (tn0 <= tf0) && (tf0 >= 0.0f) && (tn0 <= lim);
+      const bool h1 = (tn1 <= tf1) && (tf1 >= 0.0f) && (tn1 <= lim);
+      const uint32_t c0 = __float_as_uint(b0.w), c1 = __float_as_uint(b1.w);
+      const uint32_t e0 = c0 ? (kLeafBit | (c0 << 28) | __float_as_uint(a0.w)) : __float_as_uint(a0.w);
+      const uint32_t e1 = c1 ? (kLeafBit | (c1 << 28) | __float_as_uint(a1.w)) : __float_as_uint(a1.w);
+      if (h0 && h1) {
+        const bool first0 = tn0 <= tn1;
+        stk[sp * kBlock] = first0 ? e1 : e0;
+        ++sp;
+        cur = first0 ? e0 : e1;
+        continue;
+      }
+      if (h0) { cur = e0; continue; }
+      if (h1) { cur = e1; continue; }
+    } else {
+      const uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
+      for (uint32_t k = first; k < first + cnt; ++k) {
+        // Intersect::Triangle::intersects (src/Intersect.cpp:6-23)
+        const float4 q3 = S.tris[4 * k + 3];             // n, vv
+        const float4 q0 = S.tris[4 * k];                 // v0, D
+        const V3 n = v3(q3.x, q3.y, q3.z);
+        const float den = dot(n, d);
+        if (den != 0.0f) {
+          const float t = (q0.w - dot(o, n)) / den;
+          if (t >= kPrecision && t <= best.t) {
+            const float4 q1 = S.tris[4 * k + 1];         // u, uu
+            const float4 q2 = S.tris[4 * k + 2];         // v, uv
+            const V3 P = point_on_ray(o, d, t);
+            // isInTriangle (src/Intersect.cpp:24-46); u, v, uu, uv, vv are ray independent
+            const V3 w = P - v3(q0.x, q0.y, q0.z);
+            const float wu = dot(w, v3(q1.x, q1.y, q1.z)), wv = dot(w, v3(q2.x, q2.y, q2.z));
+            const float uu = q1.w, uv = q2.w, vv = q3.w;
+            const float denom = uu * vv - uv * uv;
+            const float s1 = vv * wu - uv * wv;
+            const float t1 = uu * wv - uv * wu;
+            const float s = s1 / denom;
+            const float tt = t1 / denom;
+            if (!(s < 0 || tt < 0 || s + tt > 1)) {
+              const int face = S.tri_face[k];
+              // strict < over faces in mesh order == lexicographic min of (t, face);
+              // a sphere at the same t keeps winning (src/flyscene.cpp:569, best.id < 0)
+              if (t < best.t || (t == best.t && face < best.id)) { best.t = t; best.id = face; }
+            }
+          }
+        }
+      }
+    }
+    if (sp == 0) break;
+    --sp;
+    cur = stk[sp * kBlock];
+  }
+  return best;
+}
+
+// ---------------------------------------------------------------- camera rays
+// Camera::screenToWorld + Ray ctor (tucano/camera.hpp:155-173, src/flyscene.cpp:463-465)
+__device__ __forceinline__ void camera_ray(const DevCamera& C, int x, int y, V3* o, V3* d1) {
+  const float rx = (float)x + C.sub[0], ry = (float)y + C.sub[1];
+  float nx = (float)(2.0 * (double)(rx - C.vp[0]) / (double)C.vp[2] - 1.0);
+  float ny = (float)(1.0 - 2.0 * (double)(ry - C.vp[1]) / (double)C.vp[3]);
+  const float nz = -1.0f;
+  nx *= C.aspect_scale;
+  ny *= C.scale;
+  V3 w;
+  w.x = ((C.inv34[0] * nx + C.inv34[1] * ny) + C.inv34[2] * nz) + C.inv34[3] * 1.0f;
+  w.y = ((C.inv34[4] * nx + C.inv34[5] * ny) + C.inv34[6] * nz) + C.inv34[7] * 1.0f;
+  w.z = ((C.inv34[8] * nx + C.inv34[9] * ny) + C.inv34[10] * nz) + C.inv34[11] * 1.0f;
+  const V3 org = v3(C.origin[0], C.origin[1], C.origin[2]);
+  *o = org;
+  *d1 = normalized(w - org);
+}
+// thread -> pixel of the rectangle: 16x16 tiles per block, 8x8 sub-tiles per wave
+__device__ __forceinline__ bool tile_pixel(const DevCamera& C, uint32_t block, uint32_t tid, int* px, int* py) {
+  const uint32_t tiles_x = (uint32_t)(C.w + 15) >> 4;
+  const uint32_t bx = block % tiles_x, by = block / tiles_x;
+  const uint32_t wave = tid >> 6, lane = tid & 63;
+  const int lx = (int)(bx * 16 + (wave & 1) * 8 + (lane & 7));
+  const int ly = (int)(by * 16 + (wave >> 1) * 8 + (lane >> 3));
+  *px = lx; *py = ly;
+  return lx < C.w && ly < C.h;
+}
+
+// ---------------------------------------------------------------- kernels
+// One camera ray per lane over a pixel rectangle; writes {t, id} per pixel, row-major.
+__global__ __launch_bounds__(kBlock) void k_trace_camera(DevScene S, DevCamera C, uint32_t nblocks, uint2* hits) {
+  __shared__ uint32_t stack[kStackDepth * kBlock];
+  for (uint32_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    int lx, ly;
+    if (!tile_pixel(C, blk, threadIdx.x, &lx, &ly)) continue;
+    V3 o, d1;
+    camera_ray(C, C.x0 + lx, C.y0 + ly, &o, &d1);
+    const Hit h = closest_hit(S, o, d1, stack + threadIdx.x);
+    hits[(size_t)ly * C.w + lx] = make_uint2(__float_as_uint(h.t), (uint32_t)h.id);
+  }
+}
+
+// Queued rays: rays[2i] = {o.xyz, aux}, rays[2i+1] = {d1.xyz, aux}; *count rays (device-side count).
+__global__ __launch_bounds__(kBlock) void k_trace_queue(DevScene S, const float4* rays, const uint32_t* count,
+                                                      uint32_t stride, uint2* hits) {
+  __shared__ uint32_t stack[kStackDepth * kBlock];
+  const uint32_t n = *count * stride;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float4 ro = rays[2 * (size_t)i], rd = rays[2 * (size_t)i + 1];
+    const Hit h = closest_hit(S, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), stack + threadIdx.x);
+    hits[i] = make_uint2(__float_as_uint(h.t), (uint32_t)h.id);
+  }
+}
+
+// Ray ctor over caller rays (src/Ray.h:15-18): xyz arrays -> queue records.
+__global__ void k_make_rays(const float* o, const float* d, uint32_t n, float4* rays) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const V3 d1 = normalized(v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
+  rays[2 * (size_t)i] = make_float4(o[3 * i], o[3 * i + 1], o[3 * i + 2], 0.0f);
+  rays[2 * (size_t)i + 1] = make_float4(d1.x, d1.y, d1.z, 0.0f);
+}
+
+// Unpack hit records of caller rays into the HitInfo fields (src/hitInfo.h:4-16).
+__global__ void k_unpack_hits(DevScene S, const float4* rays, const uint2* hits, uint32_t n, float* t, int* face,
+                              float* normal, float* point, int* mat) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint2 h = hits[i];
+  const float ht = __uint_as_float(h.x);
+  const int id = (int)h.y;
+  if (t) t[i] = ht;
+  if (face) face[i] = id >= 0 ? id : -1;
+  if (!normal && !point && !mat) return;
+  V3 N = v3(0, 0, 0), P = v3(0, 0, 0);
+  int m = -1;
+  if (id != -1) {
+    const float4 ro = rays[2 * (size_t)i], rd = rays[2 * (size_t)i + 1];
+    const V3 o = v3(ro.x, ro.y, ro.z), d1 = v3(rd.x, rd.y, rd.z);
+    if (id >= 0) {
+      const float4 nm = S.face_nm[id];
+      N = v3(nm.x, nm.y, nm.z); m = __float_as_int(nm.w);
+      P = point_on_ray(o, normalized(d1), ht);
+    } else {
+      const int si = -2 - id;
+      const float4 s = S.spheres[si];
+      P = point_on_ray(o, d1, ht);
+      N = normalized(P - v3(s.x, s.y, s.z));
+      m = S.sph_mat[si];
+    }
+  }
+  if (normal) { normal[3 * i] = N.x; normal[3 * i + 1] = N.y; normal[3 * i + 2] = N.z; }
+  if (point) { point[3 * i] = P.x; point[3 * i + 1] = P.y; point[3 * i + 2] = P.z; }
+  if (mat) mat[i] = m;
+}
+
+// ---------------------------------------------------------------- shading pipeline
+struct ShadeArgs {
+  DevScene S;
+  DevCamera C;
+  int gen;                  // bounce index of the rays being shaded
+  int max_bounces, reflection, shadows, skip_zero_weight;
+  uint32_t npix;            // rays of generation 0 (= pixels)
+  const float4* rays;       // generation > 0: queue records {o, pixel}, {d1, throughput}
+  const uint32_t* nrays;    // generation > 0: device-side count
+  const uint2* hits;
+  float* rgb;               // row-major, 3 floats per pixel (may be null)
+  float* out_t; int* out_face;   // generation 0 only (may be null)
+  uint32_t* parents;        // compacted list of rays that hit something
+  float4* shadow_rays;      // parents x nlights records
+  float4* next_rays;        // reflection rays of generation gen+1
+  uint32_t* counters;       // [0] = #parents, [1] = #next rays
+};
+
+struct RayRec { V3 o, d1; uint32_t pixel; float thr; bool valid; };
+
+__device__ __forceinline__ RayRec load_ray(int gen, const DevCamera& C, const float4* rays, uint32_t i) {
+  RayRec r;
+  if (gen == 0) {
+    const int x = (int)(i % (uint32_t)C.w), y = (int)(i / (uint32_t)C.w);
+    camera_ray(C, C.x0 + x, C.y0 + y, &r.o, &r.d1);
+    r.pixel = i; r.thr = 1.0f;
+  } else {
+    const float4 ro = rays[2 * (size_t)i], rd = rays[2 * (size_t)i + 1];
+    r.o = v3(ro.x, ro.y, ro.z); r.d1 = v3(rd.x, rd.y, rd.z);
+    r.pixel = __float_as_uint(ro.w); r.thr = rd.w;
+  }
+  r.valid = true;
+  return r;
+}
+
+struct Surface { V3 P, N; int mat; };
+// HitInfo point / normal / material of a hit record (src/flyscene.cpp:849-854, Intersect.cpp:167-173)
+__device__ __forceinline__ Surface surface_of(const DevScene& S, V3 o, V3 d1, float t, int id) {
+  Surface s;
+  if (id >= 0) {
+    const float4 nm = S.face_nm[id];
+    s.N = v3(nm.x, nm.y, nm.z); s.mat = __float_as_int(nm.w);
+    s.P = point_on_ray(o, normalized(d1), t);
+  } else {
+    const int si = -2 - id;
+    const float4 sp = S.spheres[si];
+    s.P = point_on_ray(o, d1, t);
+    s.N = normalized(s.P - v3(sp.x, sp.y, sp.z));
+    s.mat = S.sph_mat[si];
+  }
+  return s;
+}
+__device__ __forceinline__ DevMat default_mtl() {   // Tucano::Material::Mtl() (materials/mtl.hpp:21-39)
+  DevMat m;
+  for (int k = 0; k < 3; ++k) { m.ka[k] = 0.3f; m.kd[k] = 0.5f; m.ks[k] = 1.0f; }
+  m.ns = 10.0f; m.ni = 0.0f; m.d = 1.0f; m.illum = 0;
+  return m;
+}
+__device__ __forceinline__ DevMat material_of(const DevScene& S, int id) {
+  if (id < 0 || id >= (int)S.nmats) return default_mtl();   // materials[-1] is UB in the reference
+  return S.mats[id];
+}
+
+// wave64 compaction: returns this lane's slot in a global list, or ~0u when !want
+__device__ __forceinline__ uint32_t wave_alloc(bool want, uint32_t* counter, uint32_t per_item) {
+  const unsigned long long m = __ballot(want);
+  if (m == 0) return ~0u;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+  uint32_t base = 0;
+  const int leader = __ffsll((long long)m) - 1;
+  if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m) * per_item);
+  base = __shfl(base, leader, 64);
+  return want ? base + rank * per_item : ~0u;
+}
+
+// Flyscene::traceRay miss branch + the ray-spawning half of Shader/calculateColor
+// (src/flyscene.cpp:587-601, 686-690, 723, 747-750).
+__global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs A) {
+  const uint32_t n = A.gen == 0 ? A.npix : *A.nrays;
+  const uint32_t n_round = (n + 63u) & ~63u;    // whole waves enter the ballots
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_round; i += gridDim.x * kBlock) {
+    const bool live = i < n;
+    RayRec r; r.valid = false; r.pixel = 0; r.thr = 0; r.o = v3(0, 0, 0); r.d1 = v3(0, 0, 0);
+    float ht = INFINITY; int id = -1;
+    if (live) {
+      r = load_ray(A.gen, A.C, A.rays, i);
+      const uint2 h = A.hits[i];
+      ht = __uint_as_float(h.x); id = (int)h.y;
+      if (A.gen == 0) {
+        if (A.out_t) A.out_t[i] = ht;
+        if (A.out_face) A.out_face[i] = id >= 0 ? id : -1;
+      }
+    }
+    const bool is_hit = live && (id != -1);
+    if (live && !is_hit && A.gen == 0 && A.rgb) {
+      A.rgb[3 * (size_t)r.pixel] = (float)0.69019607843; A.rgb[3 * (size_t)r.pixel + 1] = 1.0f; A.rgb[3 * (size_t)r.pixel + 2] = 1.0f;
+    }
+    if (!A.rgb) continue;   // hits only
+    const uint32_t slot = wave_alloc(is_hit, &A.counters[0], 1);
+    Surface sf; sf.P = v3(0, 0, 0); sf.N = v3(0, 0, 0); sf.mat = -1;
+    float wr = 0.0f;
+    if (is_hit) {
+      sf = surface_of(A.S, r.o, r.d1, ht, id);
+      A.parents[slot] = i;
+      if (A.shadows) {
+        for (uint32_t l = 0; l < A.S.nlights; ++l) {
+          const float4 L = A.S.lights[l];
+          // canSeeLight: Ray(position, toLight.normalized()) normalises twice (src/flyscene.cpp:749-750)
+          const V3 d1s = normalized(normalized(v3(L.x, L.y, L.z) - sf.P));
+          const size_t k = (size_t)slot * A.S.nlights + l;
+          A.shadow_rays[2 * k] = make_float4(sf.P.x, sf.P.y, sf.P.z, 0.0f);
+          A.shadow_rays[2 * k + 1] = make_float4(d1s.x, d1s.y, d1s.z, 0.0f);
+        }
+      }
+      wr = 1.0f - material_of(A.S, sf.mat).d;
+    }
+    const bool spawn = is_hit && A.reflection && (A.gen < A.max_bounces) && !(A.skip_zero_weight && wr == 0.0f);
+    const uint32_t rs = wave_alloc(spawn, &A.counters[1], 1);
+    if (spawn) {
+      // Ray::reflectRay(hit.normal, hit.point) (src/Ray.h:32-35)
+      const V3 nd = normalized(reflect_dir(r.d1, sf.N));
+      // every light's calculateColor adds (1 - d) * reflectedColor once (src/flyscene.cpp:611-614,744)
+      const float thr = r.thr * (wr * (float)A.S.nlights);
+      A.next_rays[2 * (size_t)rs] = make_float4(sf.P.x, sf.P.y, sf.P.z, __uint_as_float(r.pixel));
+      A.next_rays[2 * (size_t)rs + 1] = make_float4(nd.x, nd.y, nd.z, thr);
+    }
+  }
+}
+
+struct ResolveArgs {
+  DevScene S;
+  DevCamera C;
+  int gen, shadows;
+  uint32_t npix;
+  const float4* rays;
+  const uint2* hits;
+  const uint32_t* parents;
+  const uint32_t* nparents;
+  const float4* shadow_rays;
+  const uint2* shadow_hits;
+  float* rgb;
+};
+
+// Flyscene::canSeeLight decision from the closest hit of the shadow ray (src/flyscene.cpp:752-781).
+// Returns visible; *bmat = blocker material id (-1: default Mtl).
+__device__ __forceinline__ bool can_see_light(const DevScene& S, V3 light, V3 P, V3 d1s, float ht, int hid, int* bmat) {
+  const float len = norm(light - P);
+  bool behind = false, sphere_block = false;
+  for (uint32_t i = 0; i < S.nspheres; ++i) {
+    const float t = ref_sphere_t(P, d1s, S.spheres[i]);
+    if (t != INFINITY && t > len) behind = true;
+    else if (t != INFINITY) sphere_block = true;
+  }
+  *bmat = -1;
+  if (ht != INFINITY && ht > len) behind = true;
+  if (ht != INFINITY && ht < len) {
+    int m = hid >= 0 ? __float_as_int(S.face_nm[hid].w) : S.sph_mat[-2 - hid];
+    *bmat = m < 0 ? -2 : m;
+  }
+  return (!sphere_block && ht == INFINITY) || behind;
+}
+
+// The local (non-recursive) part of Flyscene::calculateColor (src/flyscene.cpp:671-745), summed
+// over the point lights as Flyscene::Shader does (:611-614).
+__global__ __launch_bounds__(kBlock) void k_resolve(ResolveArgs A) {
+  const uint32_t n = *A.nparents;
+  for (uint32_t h = blockIdx.x * kBlock + threadIdx.x; h < n; h += gridDim.x * kBlock) {
+    const uint32_t i = A.parents[h];
+    const RayRec r = load_ray(A.gen, A.C, A.rays, i);
+    const uint2 hh = A.hits[i];
+    const Surface sf = surface_of(A.S, r.o, r.d1, __uint_as_float(hh.x), (int)hh.y);
+    const DevMat mat = material_of(A.S, sf.mat);
+    const float I = 0.8f / (float)A.S.nlights;
+    V3 total = v3(0, 0, 0);
+    for (uint32_t l = 0; l < A.S.nlights; ++l) {
+      const float4 Lp = A.S.lights[l];
+      const V3 light = v3(Lp.x, Lp.y, Lp.z);
+      const V3 lightDir = normalized(light - sf.P);
+      const V3 reflectedLight = reflect_dir(-lightDir, sf.N);
+      const V3 eye = normalized(r.o - sf.P);
+      const float dotted = dot(eye, normalized(reflectedLight));
+      bool visible = true; int bmat = -1;
+      if (A.shadows) {
+        const size_t k = (size_t)h * A.S.nlights + l;
+        const float4 sd = A.shadow_rays[2 * k + 1];
+        const uint2 sh = A.shadow_hits[k];
+        visible = can_see_light(A.S, light, sf.P, v3(sd.x, sd.y, sd.z), __uint_as_float(sh.x), (int)sh.y, &bmat);
+      }
+      const V3 Iv = v3(I, I, I);
+      const V3 ka = v3(mat.ka[0], mat.ka[1], mat.ka[2]);
+      const float ndl = dot(sf.N, lightDir);
+      const float md = (ndl < 0.0f) ? 0.0f : ndl;
+      const float mdot = (dotted < 0.0f) ? 0.0f : dotted;
+      V3 c;
+      if (visible) {
+        const V3 ambient = cmul(ka, Iv);
+        const V3 diffuse = md * cmul(v3(mat.kd[0], mat.kd[1], mat.kd[2]), Iv);
+        const float sp = (float)pow((double)mdot, 33.0);
+        const V3 specular = cmul(Iv, v3(mat.ks[0], mat.ks[1], mat.ks[2])) * sp;
+        c = (ambient + diffuse) + specular;
+      } else {
+        const DevMat bm = (bmat == -1) ? default_mtl() : material_of(A.S, bmat);
+        const V3 ambientS = cmul(v3(bm.ka[0], bm.ka[1], bm.ka[2]), Iv);
+        const V3 diffuseS = md * cmul(v3(bm.kd[0], bm.kd[1], bm.kd[2]), Iv);
+        const float spS = powf(mdot, bm.ns);
+        const V3 specularS = cmul(Iv, v3(bm.ks[0], bm.ks[1], bm.ks[2])) * spS;
+        const V3 colorS = (ambientS + diffuseS) + specularS;
+        c = cmul(ka, Iv) + colorS * bm.d;
+      }
+      total = total + c;
+    }
+    float* px = A.rgb + 3 * (size_t)r.pixel;
+    if (A.gen == 0) { px[0] = total.x; px[1] = total.y; px[2] = total.z; }
+    else { px[0] += r.thr * total.x; px[1] += r.thr * total.y; px[2] += r.thr * total.z; }
+  }
+}
+
+// canSeeLight over caller (light, position) pairs: ray construction and decision.
+__global__ void k_make_shadow_rays(const float* light, const float* pos, uint32_t n, float4* rays) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const V3 P = v3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+  const V3 L = v3(light[3 * i], light[3 * i + 1], light[3 * i + 2]);
+  const V3 d1s = normalized(normalized(L - P));
+  rays[2 * (size_t)i] = make_float4(P.x, P.y, P.z, 0.0f);
+  rays[2 * (size_t)i + 1] = make_float4(d1s.x, d1s.y, d1s.z, 0.0f);
+}
+__global__ void k_visible(DevScene S, const float* light, const float4* rays, const uint2* hits, uint32_t n,
+                          unsigned char* visible, int* bmat) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 ro = rays[2 * (size_t)i], rd = rays[2 * (size_t)i + 1];
+  const uint2 h = hits[i];
+  int bm;
+  const bool v = can_see_light(S, v3(light[3 * i], light[3 * i + 1], light[3 * i + 2]), v3(ro.x, ro.y, ro.z),
+                               v3(rd.x, rd.y, rd.z), __uint_as_float(h.x), (int)h.y, &bm);
+  visible[i] = v ? 1 : 0;
+  if (bmat) bmat[i] = bm;
+}
+
+}  // namespace rtx

@@ -1,0 +1,58 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_bits_equal(a, b, what=""):
+    """Bit equality of float arrays, NaNs compared by position only."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    assert a.shape == b.shape, what
+    na, nb = np.isnan(a), np.isnan(b)
+    assert np.array_equal(na, nb), what + ": NaN positions differ"
+    bad = (bits(a) != bits(b)) & ~na
+    assert not bad.any(), "%s: %d of %d values differ, first at %s" % (what, bad.sum(), bad.size,
+                                                                         np.argwhere(bad)[:3].tolist())
+
+
+def load_scene_fixture(name):
+    z = np.load(os.path.join(GOLDEN, "scene_%s.npz" % name))
+    return {k: z[k] for k in z.files}
+
+
+def oracle_materials(arr):
+    from oracle import oracle_api as oa
+    return [oa.make_mtl(ka=tuple(m[0:3]), kd=tuple(m[3:6]), ks=tuple(m[6:9]), ns=m[9], ni=m[10], d=m[11],
+                        illum=int(m[12])) for m in arr]
+
+
+def rtx_materials(arr):
+    from raytracing_project_amd import api
+    return [api.make_material(ka=tuple(m[0:3]), kd=tuple(m[3:6]), ks=tuple(m[6:9]), ns=m[9], ni=m[10], d=m[11],
+                              illum=int(m[12])) for m in arr]
+
+
+SCENES = ["planeobj", "cube", "twoObjects", "test", "plane", "spheres", "toy", "dodgeColorTest"]
+CAMS = ["default", "oblique", "top"]
+
+
+@pytest.fixture(scope="session")
+def oa():
+    from oracle import oracle_api
+    oracle_api.build()
+    return oracle_api

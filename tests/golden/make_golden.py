@@ -1,0 +1,187 @@
+"""Generates the committed golden fixtures.  Runs only where /root/reference exists.
+
+  primitives.npz   seeded inputs + outputs of the REFERENCE's own code (oracle/_ref/libref.so =
+                   src/Intersect.cpp, src/Ray.h, tucano/camera.hpp compiled in place)
+  scene_*.npz      bundled OBJ scenes flattened by the Tucano-order loader restatement
+                   (inputs) + closest-hit / shading dumps of the C oracle at 48x48 (outputs)
+  survey_observations.json  outputs of the unmodified reference recorded in SURVEY.md 8(c)
+
+Usage: python tests/golden/make_golden.py
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle_api as oa  # noqa: E402
+from raytracing_project_amd import scenes  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MODELS = "/root/reference/resources/models"
+fp = oa.fp
+f32 = lambda a: np.ascontiguousarray(a, np.float32)
+
+
+def primitives(n=3000, seed=20261111):
+    R = oa.ref()
+    assert R is not None, "oracle/_ref/libref.so missing: run make -C oracle"
+    rng = np.random.default_rng(seed)
+    out = {k: [] for k in ("o", "d", "v", "nq", "tri", "plane", "bmin", "bmax", "box", "c", "r", "sphere", "ray",
+                           "p", "reflect", "view", "n12", "refract", "resend", "nface", "view34", "wh", "ij",
+                           "cam_world", "cam_center")}
+    for it in range(n):
+        o = f32(rng.uniform(-2, 2, 3))
+        d = f32(rng.uniform(-1, 1, 3))
+        v = f32(rng.uniform(-1, 1, (3, 3)))
+        if it % 3 == 0:
+            w = rng.dirichlet([1, 1, 1])
+            d = f32((w[:, None] * v).sum(0) - o)
+        if it % 50 == 0:
+            d[it % 3] = 0.0          # axis-parallel rays (1/0 in the slab test)
+        if it % 97 == 0:
+            v[2] = v[1]              # degenerate triangle
+        nf = np.zeros(3, np.float32)
+        R.ref_face_normal(fp(v[0]), fp(v[1]), fp(v[2]), fp(nf))
+        nq = np.zeros(3, np.float32)
+        R.ref_renormal(fp(nf), fp(nq))
+        h = np.zeros(7, np.float32)
+        R.ref_triangle(fp(o), fp(d), fp(v[0]), fp(v[1]), fp(v[2]), fp(nq), fp(h))
+        tri = h.copy()
+        R.ref_plane(fp(o), fp(d), fp(v[0]), fp(nq), fp(h))
+        plane = h.copy()
+        bmin = f32(np.minimum(v[0], v[1]))
+        bmax = f32(np.maximum(v[0], v[1]))
+        box = R.ref_box(fp(o), fp(d), fp(bmin), fp(bmax))
+        c = f32(rng.uniform(-1, 1, 3))
+        r = np.float32(rng.uniform(0.05, 0.8))
+        ds = f32(c + rng.normal(0, r * 0.7, 3) - o) if it % 2 == 0 else d
+        R.ref_sphere(fp(o), fp(ds), fp(c), float(r), fp(h))
+        sph = h.copy()
+        a = np.zeros(3, np.float32)
+        b = np.zeros(3, np.float32)
+        R.ref_ray(fp(o), fp(d), fp(a), fp(b))
+        ray = np.r_[a, b]
+        p = f32(rng.uniform(-1, 1, 3))
+        R.ref_reflect(fp(o), fp(d), fp(nq), fp(p), fp(a), fp(b))
+        refl = np.r_[a, b]
+        view = rng.uniform(-1, 1, 3)
+        view = f32(view / np.linalg.norm(view))
+        n12 = (1.0, float(np.float32(rng.uniform(0.5, 2)))) if it % 2 else (float(np.float32(rng.uniform(0.5, 2))), 1.0)
+        R.ref_refract(fp(o), fp(d), fp(nq), fp(p), fp(view), n12[0], n12[1], fp(a), fp(b))
+        refr = np.r_[a, b]
+        dd = np.zeros(24, np.float32)
+        R.ref_resend(fp(o), fp(d), fp(nq), fp(p), 8, fp(dd))
+        A = rng.normal(size=(3, 3))
+        Q, _ = np.linalg.qr(A)
+        if it % 4 == 0:
+            Q = np.eye(3)
+        view34 = f32(np.c_[Q, rng.uniform(-3, 3, 3)])
+        if it % 8 == 0:
+            view34 = scenes.default_view()
+        W, H = [(64, 64), (1920, 1080), (512, 512), (3840, 2160)][it % 4]
+        i = float(rng.integers(0, W))
+        j = float(rng.integers(0, H))
+        w3 = np.zeros(3, np.float32)
+        ce = np.zeros(3, np.float32)
+        R.ref_camera(fp(view34.reshape(-1)), W, H, 60.0, float(np.float32(W) / np.float32(H)), i, j, fp(w3), fp(ce))
+        for k, val in (("o", o), ("d", d), ("v", v), ("nq", nq), ("tri", tri), ("plane", plane), ("bmin", bmin),
+                       ("bmax", bmax), ("box", np.float32(box)), ("c", c), ("r", r), ("sphere", np.r_[ds, sph]),
+                       ("ray", ray), ("p", p), ("reflect", refl), ("view", view), ("n12", f32(n12)),
+                       ("refract", refr), ("resend", dd.copy()), ("nface", nf), ("view34", view34),
+                       ("wh", f32([W, H])), ("ij", f32([i, j])), ("cam_world", w3), ("cam_center", ce)):
+            out[k].append(val)
+    np.savez_compressed(os.path.join(HERE, "primitives.npz"), **{k: np.asarray(v) for k, v in out.items()})
+
+
+def mtl_array(mats):
+    return np.array([[*m.ka, *m.kd, *m.ks, m.ns, m.ni, m.d, float(m.illum)] for m in mats], np.float32).reshape(-1, 13)
+
+
+CAMERAS = {
+    "default": None,   # Flycamera default: centre (0,0,2), looking down -z
+    "oblique": ((1.6, 1.1, 1.9), (0.0, 0.1, 0.0)),
+    "top": ((0.2, 3.0, 0.3), (0.0, 0.0, 0.0)),
+}
+
+
+def scene_fixture(name, res=48):
+    verts, idx, tm, mats, names = oa.obj_load(os.path.join(MODELS, name + ".obj"))
+    out = {"verts": verts, "idx": idx, "tri_mat": tm, "mats": mtl_array(mats), "res": np.int32(res)}
+    s = oa.Scene(verts, idx, tm, mats)
+    s.set_lights([[-1.0, 1.0, 1.0]])                       # src/flyscene.cpp:48
+    lo, hi = verts.min(0), verts.max(0)
+    ctr, rad = (lo + hi) / 2, float(np.linalg.norm(hi - lo) / 2)
+    out["leaves"] = np.int32(s.build_leafboxes())          # -1 where divideBox_KD never terminates
+    for cname, cam in CAMERAS.items():
+        if cam is None:
+            view = scenes.default_view()
+        else:
+            eye = ctr + rad * np.asarray(cam[0]) / 1.5
+            view = scenes.look_at_view(eye, ctr + np.asarray(cam[1]))
+        c = oa.make_camera(view, res, res)
+        out["view_" + cname] = view
+        # closest hit only
+        _, t, face = s.render(c, (0, 0, res, res), threads=8, want_rgb=False)
+        out["t_" + cname], out["face_" + cname] = t, face
+        has_mat = bool((tm >= 0).all())
+        if has_mat:
+            # north-star options: primary + shadow + reflection chain (depth 2), no refraction / GI
+            s.set_options(max_bounces=2, reflection=1, refraction=0, gi_rays=0, shadows=1, skip_zero_weight=0)
+            rgb, _, _ = s.render(c, (0, 0, res, res), threads=8, want_hits=False)
+            out["rgb_ns_" + cname] = rgb
+            if out["leaves"] > 0 and len(idx) < 1000:
+                s.set_options()                                # the reference itself
+                rgb, _, _ = s.render(c, (0, 0, res, res), threads=8, want_hits=False)
+                out["rgb_ref_" + cname] = rgb
+    np.savez_compressed(os.path.join(HERE, "scene_%s.npz" % name), **out)
+    print(name, len(verts), len(idx), len(mats), "leaves", int(out["leaves"]))
+
+
+def default_scene_with_spheres(res=48):
+    """The reference's real render state: planeobj + 13 spheres (src/flyscene.cpp:452-458)."""
+    verts, idx, tm, mats, _ = oa.obj_load(os.path.join(MODELS, "planeobj.obj"))
+    s = oa.Scene(verts, idx, tm, mats)
+    s.set_lights([[-1.0, 1.0, 1.0]])
+    s.build_leafboxes()
+    cr, ka, kd = scenes.reference_spheres()
+    ids = [s.add_material(oa.make_mtl(ka=tuple(ka[i]), kd=tuple(kd[i]), ks=(.5, .5, .5), ns=10, ni=1, d=0, illum=2))
+           for i in range(len(cr))]
+    s.set_spheres(cr, ids)
+    out = {"res": np.int32(res)}
+    for cname, cam in CAMERAS.items():
+        view = scenes.default_view() if cam is None else scenes.look_at_view(np.asarray(cam[0]) * 1.5, cam[1])
+        c = oa.make_camera(view, res, res)
+        out["view_" + cname] = view
+        _, t, face = s.render(c, (0, 0, res, res), threads=8, want_rgb=False)
+        out["t_" + cname], out["face_" + cname] = t, face
+        s.set_options(max_bounces=2, reflection=1, refraction=0, gi_rays=0, shadows=1, skip_zero_weight=0)
+        out["rgb_ns_" + cname] = s.render(c, (0, 0, res, res), threads=8, want_hits=False)[0]
+        s.set_options()
+        out["rgb_ref_" + cname] = s.render(c, (0, 0, res, res), threads=8, want_hits=False)[0]
+    np.savez_compressed(os.path.join(HERE, "default_spheres.npz"), **out)
+
+
+def survey_observations():
+    obs = {
+        "source": "SURVEY.md section 8(c): outputs of the unmodified reference (flyscene.cpp + Intersect.cpp) run headless",
+        "scene": "planeobj", "viewport": 64, "faces": 14, "verts": 12, "mats": 2, "boxes": 4,
+        "root_min": [-2.0, 0.0, -2.0], "root_max": [2.0, 0.3, 2.0],
+        "pixel_32_32": {"t": 2.0, "faceId": 5, "material_id": 0},
+        "primaries_hitting_a_triangle": 243,
+        "traceRay_32_40": [0.690196097, 1.0, 1.0],
+        "with_spheres_center_pixel_64_and_128": [0.213333353, 0.177866668, 0.0],
+    }
+    json.dump(obs, open(os.path.join(HERE, "survey_observations.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    oa.build(force=True)
+    primitives()
+    for name in ("planeobj", "cube", "twoObjects", "test", "plane", "spheres", "toy", "dodgeColorTest"):
+        scene_fixture(name)
+    default_scene_with_spheres()
+    survey_observations()
