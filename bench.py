@@ -1,0 +1,303 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (primary + shadow + reflection) of the HIP ray-scene
+intersection path, one process per GPU.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one frame of the workload: every rank renders its image tiles
+(rtx_render_tiles_dev, scene replicated per GPU), then the framebuffer (rgb + face id) is
+gathered to rank 0 (RCCL).  value = rays traced by all ranks in the K timed frames / wall
+time (max over ranks).  Total work is fixed as N grows: "strong" scaling.
+
+The JSON line also carries
+  roofline      for the dominant traversal kernel: algorithmic bytes (SURVEY 8(d):
+                32 B per node visited + 36 B per triangle tested + io per ray, counted by the
+                CPU mirror traversal of the same BVH on a strided sample of the same rays)
+                divided by that kernel's HIP-event duration, against 8 TB/s;
+  cpu_baseline  the CPU oracle (brute-force reference path) timed on this host on a bounded
+                sample of the same rays.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+TILE = 32
+
+
+def build_workload(name, api, scenes):
+    """-> dict(verts, idx, tri_mat, mats (rtx), omats (kwargs for the oracle), lights, view, W, H, opts, spp)"""
+    mk = dict
+    if name == "soup1M_4k_primary_shadow":
+        verts, idx = scenes.soup(1000000, seed=0x5EED0001, h=0.02)
+        m = mk(ka=(0, 0, 0), kd=(.7, .7, .7), ks=(.2, .2, .2), ns=10.0, ni=0.0, d=1.0, illum=2)
+        return dict(verts=verts, idx=idx, tri_mat=np.zeros(len(idx), np.int32), mats=[m], lights=[[-2.0, 2.0, 2.0]],
+                    view=scenes.look_at_view((0, 0, 3), (0, 0, 0)), W=3840, H=2160, opts=(0, 1, 0, 0, 1, 1), spp=1)
+    if name == "soup5M_4k_16l_16spp":
+        verts, idx = scenes.soup(5000000, seed=0x5EED0005, h=0.012)
+        m = mk(ka=(0, 0, 0), kd=(.7, .7, .7), ks=(.2, .2, .2), ns=10.0, ni=0.0, d=1.0, illum=2)
+        lights = [[3 * np.cos(2 * np.pi * k / 16), 2.0, 3 * np.sin(2 * np.pi * k / 16)] for k in range(16)]
+        return dict(verts=verts, idx=idx, tri_mat=np.zeros(len(idx), np.int32), mats=[m], lights=lights,
+                    view=scenes.look_at_view((0, 0, 3), (0, 0, 0)), W=3840, H=2160, opts=(0, 1, 0, 0, 1, 1), spp=16)
+    if name == "bunny70k_1080p_primary_shadow":
+        verts, idx = scenes.blob()
+        lo, hi = verts.min(0), verts.max(0)
+        c, r = (lo + hi) / 2, float(np.linalg.norm(hi - lo) / 2)
+        m = mk()   # Tucano Mtl() defaults
+        return dict(verts=verts, idx=idx, tri_mat=np.zeros(len(idx), np.int32), mats=[m],
+                    lights=[list(c + r * np.array([-1.0, 1.0, 1.0]))],
+                    view=scenes.look_at_view(c + np.array([0, 0, 2 * r]), c), W=1920, H=1080, opts=(0, 1, 0, 0, 1, 1), spp=1)
+    if name == "hall262k_1080p_reflect3":
+        verts, idx, tm = scenes.hall()
+        wall = mk(ka=(.1, .1, .1), kd=(.6, .55, .5), ks=(.3, .3, .3), ns=20.0, ni=1.0, d=0.5, illum=2)
+        col = mk(ka=(.1, .1, .1), kd=(.5, .6, .7), ks=(.6, .6, .6), ns=40.0, ni=1.0, d=0.5, illum=2)
+        return dict(verts=verts, idx=idx, tri_mat=tm, mats=[wall, col], lights=[[0.0, 2.7, 0.0]],
+                    view=scenes.look_at_view((0.3, 1.6, 7.0), (0.0, 1.2, 0.0)), W=1920, H=1080, opts=(3, 1, 0, 0, 1, 1), spp=1)
+    if name == "planeobj_512_primary_shadow":
+        z = np.load(os.path.join(ROOT, "tests", "golden", "scene_planeobj.npz"))
+        mats = [mk(ka=tuple(m[0:3]), kd=tuple(m[3:6]), ks=tuple(m[6:9]), ns=float(m[9]), ni=float(m[10]), d=float(m[11]),
+                   illum=int(m[12])) for m in z["mats"]]
+        return dict(verts=z["verts"], idx=z["idx"], tri_mat=z["tri_mat"], mats=mats, lights=[[-1.0, 1.0, 1.0]],
+                    view=scenes.default_view(), W=512, H=512, opts=(0, 1, 0, 0, 1, 1), spp=1)
+    raise SystemExit("unknown workload %s" % name)
+
+
+WORKLOADS = ["soup1M_4k_primary_shadow", "bunny70k_1080p_primary_shadow", "hall262k_1080p_reflect3",
+             "soup5M_4k_16l_16spp", "planeobj_512_primary_shadow"]
+
+
+def spp_offsets(spp):
+    if spp == 1:
+        return [(0.0, 0.0)]          # the reference's top-left sample
+    n = int(round(spp ** 0.5))
+    return [((a + .5) / n, (b + .5) / n) for b in range(n) for a in range(n)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=WORKLOADS[0], choices=WORKLOADS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=6144, help="primary rays in the cpu_baseline sample")
+    ap.add_argument("--roofline-stride", type=int, default=16, help="every k-th pixel feeds the byte count")
+    args = ap.parse_args()
+
+    import torch
+    from raytracing_project_amd import api, scenes, tiles
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with that many ranks" % args.gpus)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    wl = build_workload(args.workload, api, scenes)
+    W, H = wl["W"], wl["H"]
+    scene = api.Scene(wl["verts"], wl["idx"], wl["tri_mat"], [api.make_material(**m) for m in wl["mats"]])
+    scene.set_lights(wl["lights"])
+    scene.commit(local_rank)
+    info = scene.info()
+    opts = api.Options(*wl["opts"])
+    offsets = spp_offsets(wl["spp"])
+    cams = [api.make_camera(wl["view"], W, H, subpixel=o) for o in offsets]
+    rect = (0, 0, W, H)
+    kmax = tiles.max_local_tiles(W, H, TILE, world)
+    npix_local = kmax * TILE * TILE
+    rgb = torch.zeros((npix_local, 3), dtype=torch.float32, device=dev)
+    acc = torch.zeros_like(rgb) if len(cams) > 1 else None
+    face = torch.full((npix_local, 1), -1, dtype=torch.int32, device=dev)
+
+    def frame():
+        """One frame: render my tiles (all spp passes), gather to rank 0, assemble."""
+        rays = [0, 0, 0]
+        ms = [0.0, 0.0, 0.0]
+        if acc is not None:
+            acc.zero_()
+        for cam in cams:
+            # librtx runs on its own HIP stream: torch work touching rgb/face must be done first
+            torch.cuda.current_stream().synchronize()
+            scene.render_tiles_dev(cam, opts, rect, TILE, rank, world, rgb.data_ptr(), None, face.data_ptr())
+            st = scene.stats()
+            rays[0] += st.rays_primary
+            rays[1] += st.rays_shadow
+            rays[2] += st.rays_reflection
+            ms[0] += st.ms_trace_camera
+            ms[1] += st.ms_trace - st.ms_trace_camera
+            ms[2] += st.ms_total
+            if acc is not None:
+                acc.add_(rgb)
+        out = rgb if acc is None else acc.mul_(1.0 / len(cams))
+        g_rgb = tiles.gather_to_root(out, world, rank, dist)
+        g_face = tiles.gather_to_root(face, world, rank, dist)
+        img = None
+        if rank == 0:
+            img = (tiles.assemble(g_rgb, W, H, TILE, 3), tiles.assemble(g_face, W, H, TILE, 1))
+        return rays, ms, img
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        frame()
+    sync()
+    t0 = time.perf_counter()
+    rays_tot = np.zeros(3, np.int64)
+    ms_tot = np.zeros(3, np.float64)
+    for _ in range(args.steps):
+        r, m, img = frame()
+        rays_tot += r
+        ms_tot += m
+    sync()
+    dt = time.perf_counter() - t0
+    # whole-job aggregates: rays summed over ranks, time = max over ranks
+    agg = torch.tensor([float(rays_tot[0]), float(rays_tot[1]), float(rays_tot[2])], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(agg)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    total_rays = float(agg.sum().item())
+    dt = float(tmax.item())
+
+    result = None
+    if rank == 0:
+        hits = int((img[1] >= 0).sum().item())
+        result = {
+            "metric": "Mrays/sec (primary+shadow+reflection)", "value": total_rays / dt / 1e6, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "triangles": int(info.ntris), "bvh_nodes": int(info.nnodes),
+                       "image": [W, H], "lights": len(wl["lights"]), "spp": wl["spp"], "max_bounces": wl["opts"][0],
+                       "tile": TILE, "partition": "image tiles round-robin over %d rank(s), scene replicated, gather to rank 0" % world,
+                       "rays_per_frame": {"primary": int(agg[0].item() / args.steps), "shadow": int(agg[1].item() / args.steps),
+                                          "reflection": int(agg[2].item() / args.steps)},
+                       "pixels_hitting_geometry": hits,
+                       "kernel_ms_per_frame_rank0": {"trace_camera": ms_tot[0] / args.steps,
+                                                      "trace_queue": ms_tot[1] / args.steps,
+                                                      "all_kernels": ms_tot[2] / args.steps}},
+        }
+    if rank == 0 and world == 1 and not args.no_roofline:
+        result["roofline"] = roofline(args, wl, scene, info, ms_tot / args.steps, rays_tot / args.steps)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args, wl)
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    scene.close()
+
+
+def oracle_scene(wl):
+    from oracle import oracle_api as oa
+    oa.build()
+    s = oa.Scene(wl["verts"], wl["idx"], wl["tri_mat"], [oa.make_mtl(**m) for m in wl["mats"]])
+    s.set_lights(wl["lights"])
+    return oa, s
+
+
+def roofline(args, wl, scene, info, ms, rays):
+    """Algorithmic bytes of the dominant traversal kernel / its measured duration vs HBM peak."""
+    oa, osc = oracle_scene(wl)
+    W, H = wl["W"], wl["H"]
+    stride = max(1, args.roofline_stride)
+    nodes, order = scene.bvh()
+    tris = scene.tris()
+    lo, hi = osc.root_box()
+    ocam = oa.make_camera(wl["view"], W, H)
+    o, d1 = oa.camera_rays(ocam, (0, 0, W, H))
+    pick = np.arange(0, W * H, stride)
+    threads = min(16, os.cpu_count() or 1)
+    t, f, nv, tt = oa.bvh_trace(nodes, tris, order, lo, hi, o[pick], d1[pick], threads=threads, nwild=info.nwild)
+    prim_bytes = (32.0 * nv.sum() + 36.0 * tt.sum()) * stride + 8.0 * W * H
+    res = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+           "bytes_model": "32 B/node visited + 36 B/triangle tested + io (8 B/primary, 72 B/queued ray), counts from the CPU "
+                          "mirror traversal of the same BVH on every %d-th pixel, scaled" % stride,
+           "per_ray": {"primary_nodes": float(nv.mean()), "primary_tris": float(tt.mean())}}
+    # shadow rays of the sampled pixels that hit something (first light only; scaled by the light count)
+    hit = f >= 0
+    sh_bytes = 0.0
+    if hit.any() and wl["opts"][4]:
+        # hit points / shadow directions in numpy fp32: ulp-level differences from the kernel's
+        # own values do not move the visit counts
+        dd = d1[pick][hit]
+        d2 = dd / np.sqrt((dd * dd).sum(1, dtype=np.float32))[:, None]
+        P = (o[pick][hit] + t[hit, None] * d2).astype(np.float32)
+        L = np.float32(wl["lights"][0])
+        sd = (L[None] - P).astype(np.float32)
+        sd1 = (sd / np.sqrt((sd * sd).sum(1, dtype=np.float32))[:, None]).astype(np.float32)
+        _, _, nv2, tt2 = oa.bvh_trace(nodes, tris, order, lo, hi, P, sd1, threads=threads, nwild=info.nwild)
+        nl = len(wl["lights"])
+        sh_bytes = ((32.0 * nv2.sum() + 36.0 * tt2.sum()) + 72.0 * len(P)) * stride * nl
+        res["per_ray"].update({"shadow_nodes": float(nv2.mean()), "shadow_tris": float(tt2.mean())})
+    spp = wl["spp"]
+    cand = [("k_trace_camera", prim_bytes * spp, ms[0]), ("k_trace_queue(shadow)", sh_bytes * spp, ms[1])]
+    if wl["opts"][0] > 0:     # reflection launches share k_trace_queue's time; only the camera kernel is attributable
+        cand = cand[:1]
+    name, nbytes, kms = max(cand, key=lambda c: c[2])
+    launches = spp if name == "k_trace_camera" else spp
+    res.update({"kernel": name, "achieved": nbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0,
+                "algorithmic_bytes_per_launch": nbytes / launches, "avg_launch_ms": kms / launches})
+    res["frac"] = res["achieved"] / HBM_PEAK_GBS
+    return res
+
+
+def cpu_baseline(args, wl):
+    """The reference CPU path (brute force over all triangles, oracle port) on a bounded sample."""
+    oa, osc = oracle_scene(wl)
+    W, H = wl["W"], wl["H"]
+    ntri = len(wl["idx"])
+    # ~15 s of work at ~6e7 triangle tests / s / core
+    cores = min(16, os.cpu_count() or 1)
+    budget = 6e7 * cores * 12.0
+    n = int(max(256, min(args.cpu_sample * 64, budget / max(ntri, 1) / 1.6)))
+    n = min(n, W * H)
+    stride = max(1, (W * H) // n)
+    pick = np.arange(0, W * H, stride)[:n]
+    ocam = oa.make_camera(wl["view"], W, H)
+    org, dirs = oa.camera_rays(ocam, (0, 0, W, H))
+    org, dirs = org[pick].copy(), dirs[pick].copy()
+    t0 = time.perf_counter()
+    h = osc.closest(org, dirs, threads=cores)                    # primary rays, Flyscene::getIntersections
+    hit = h["t"] != np.inf
+    nrays = len(pick)
+    if hit.any() and wl["opts"][4]:
+        P = h["p"][hit]
+        for L in wl["lights"][:1]:
+            sd = (np.float32(L)[None] - P).astype(np.float32)
+            osc.closest(P, sd, threads=cores)                    # shadow rays: closest hit, as canSeeLight does
+            nrays += len(P)
+    dt = time.perf_counter() - t0
+    return {"value": nrays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "%d primary rays (every %d-th pixel) + %d shadow rays of %s, brute force over %d triangles "
+                      "(reference algorithm, oracle/rt_oracle.c), %.1f s" % (len(pick), stride, nrays - len(pick),
+                                                                             args.workload, ntri, dt)}
+
+
+if __name__ == "__main__":
+    main()

@@ -69,13 +69,14 @@ typedef struct {
   float ms_trace;      /* HIP-event time of the traversal kernels (sum over launches) */
   float ms_total;      /* HIP-event time of every kernel of the call */
   uint32_t launches_trace;
-  uint32_t reserved;
+  float ms_trace_camera;   /* the primary-ray traversal launch alone (0 when the call had none) */
 } rtx_stats;
 
 typedef struct {
   uint32_t ntris, nverts, nnodes, nleaves, max_depth, nspheres, nlights, nmaterials;
   uint64_t device_bytes;
   float build_ms;
+  uint32_t nwild;     /* ill-conditioned triangles kept out of the BVH (tested by every ray) */
 } rtx_scene_info;
 
 const char* rtx_last_error(void);
@@ -106,7 +107,8 @@ int rtx_scene_build(rtx_scene*);
 int rtx_scene_commit(rtx_scene*, int device);
 int rtx_scene_get_info(const rtx_scene*, rtx_scene_info*);
 /* Host copy of the flattened acceleration structure (tests / roofline accounting).
- * nodes: nnodes x 8 words {lo.xyz, leftOrFirst, hi.xyz, count}; tri_face: ntris ids in leaf order. */
+ * nodes: nnodes x 8 words {lo.xyz, leftOrFirst, hi.xyz, count}; tri_face: ntris ids in leaf order,
+ * the last rtx_scene_info.nwild of them being the triangles outside the hierarchy. */
 int rtx_scene_get_bvh(const rtx_scene*, uint32_t* nodes8, uint32_t* tri_face);
 /* Host copy of the leaf-ordered 64-byte triangle records: ntris x 16 floats
  * {v0.xyz, D}{u.xyz, u.u}{v.xyz, u.v}{n.xyz, v.v} (src/Intersect.cpp:10,26-32 hoisted per triangle). */
@@ -133,6 +135,17 @@ int rtx_render(rtx_scene*, const rtx_camera*, const rtx_options*, rtx_rect rect,
                float* rgb, float* t, int32_t* face_id);
 int rtx_render_dev(rtx_scene*, const rtx_camera*, const rtx_options*, rtx_rect rect,
                    float* rgb, float* t, int32_t* face_id);
+
+/* The row-strided thread decomposition of raytraceScene (src/flyscene.cpp:418-430,460) as an
+ * image-tile partition for several GPUs: `rect` is cut into tile_size x tile_size tiles
+ * (row-major tile order), part p of nparts renders tiles p, p + nparts, ... and stores its
+ * k-th tile at output pixels [k*tile_size^2, (k+1)*tile_size^2), row-major inside the tile
+ * (slots of partial edge tiles that fall outside `rect` are left untouched).
+ * rtx_tiles_count returns how many tiles that part owns (>= 0), or a negative error. */
+int rtx_tiles_count(rtx_rect rect, int32_t tile_size, int32_t part, int32_t nparts);
+int rtx_render_tiles_dev(rtx_scene*, const rtx_camera*, const rtx_options*, rtx_rect rect,
+                         int32_t tile_size, int32_t part, int32_t nparts,
+                         float* rgb, float* t, int32_t* face_id);
 
 int rtx_get_stats(const rtx_scene*, rtx_stats*);
 

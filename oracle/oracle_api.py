@@ -110,7 +110,7 @@ def lib():
         L.ora_resend.argtypes = [_f, _f, _f, _f, C.c_int, _f]
         L.ora_points_on_circle.argtypes = [_f, C.c_float, _f, C.c_int, _f]
         L.ora_points_on_circle.restype = C.c_int
-        L.ora_bvh_trace.argtypes = [C.POINTER(C.c_uint32), _f, C.POINTER(C.c_int32), C.c_uint32, _f, _f, _f, _f,
+        L.ora_bvh_trace.argtypes = [C.POINTER(C.c_uint32), _f, C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, _f, _f, _f, _f,
                                     C.c_int, C.c_int, _f, C.POINTER(C.c_int32), C.POINTER(C.c_uint32),
                                     C.POINTER(C.c_uint32)]
         L.ora_bvh_trace.restype = None
@@ -120,7 +120,7 @@ def lib():
     return _lib
 
 
-def bvh_trace(nodes8, tri16, tri_face, root_lo, root_hi, o, d1, threads=1):
+def bvh_trace(nodes8, tri16, tri_face, root_lo, root_hi, o, d1, threads=1, nwild=0):
     """CPU mirror of the GPU traversal over the BVH exported by librtx: (t, face, nodes_visited, tris_tested)."""
     nodes8 = np.ascontiguousarray(nodes8, np.uint32)
     tri16 = np.ascontiguousarray(tri16, np.float32)
@@ -135,7 +135,7 @@ def bvh_trace(nodes8, tri16, tri_face, root_lo, root_hi, o, d1, threads=1):
     nv = np.zeros(n, np.uint32)
     tt = np.zeros(n, np.uint32)
     lib().ora_bvh_trace(nodes8.ctypes.data_as(C.POINTER(C.c_uint32)), fp(tri16),
-                        tri_face.ctypes.data_as(C.POINTER(C.c_int32)), len(tri_face), fp(rl), fp(rh), fp(o), fp(d1),
+                        tri_face.ctypes.data_as(C.POINTER(C.c_int32)), len(tri_face), nwild, fp(rl), fp(rh), fp(o), fp(d1),
                         n, threads, fp(t), face.ctypes.data_as(C.POINTER(C.c_int32)),
                         nv.ctypes.data_as(C.POINTER(C.c_uint32)), tt.ctypes.data_as(C.POINTER(C.c_uint32)))
     return t, face, nv, tt

@@ -123,7 +123,7 @@ void ora_ray_counts(const ora_scene*, uint64_t out[5]);
 void ora_closest_mt(const ora_scene*, const float* o, const float* d, int n, int threads, ora_hit* out);
 
 /* --- BVH traversal mirror (rt_oracle_bvh.c): checker for the exported BVH + visit counters */
-void ora_bvh_trace(const uint32_t* nodes8, const float* tri16, const int32_t* tri_face, uint32_t ntris,
+void ora_bvh_trace(const uint32_t* nodes8, const float* tri16, const int32_t* tri_face, uint32_t ntris, uint32_t nwild,
                    const float* root_lo, const float* root_hi, const float* o, const float* d1, int n, int threads,
                    float* t, int32_t* face, uint32_t* nodes_visited, uint32_t* tris_tested);
 void ora_camera_rays(const ora_camera* cam, int x0, int y0, int x1, int y1, float* o, float* d1);

@@ -29,7 +29,7 @@ static inline void normalize3f(const float* a, float* out) {
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
 typedef struct {
-  const uint32_t* nodes; const float* tris; const int32_t* tri_face; uint32_t ntris;
+  const uint32_t* nodes; const float* tris; const int32_t* tri_face; uint32_t ntris, nwild;
   const float* root_lo; const float* root_hi;
   const float* o; const float* d1; int n, tid, nthreads;
   float* t; int32_t* face; uint32_t* nodes_visited; uint32_t* tris_tested;
@@ -58,6 +58,29 @@ static void slab(const uint32_t* node, const float* iv, const float* oi, float* 
   *tf = fminf(fminf(fmaxf(a[0], b[0]), fmaxf(a[1], b[1])), fmaxf(a[2], b[2]));
 }
 
+/* Intersect::Triangle::intersects on the hoisted record (src/Intersect.cpp:6-46) */
+static void tri_test(const bvh_job* j, uint32_t k, const float* o, const float* d, float* best_t, int* best_id) {
+  const float* q = j->tris + 16 * (size_t)k;
+  const float* nrm = q + 12;
+  float den = dot3f(nrm, d);
+  if (den != 0.0f) {
+    float t = (q[3] - dot3f(o, nrm)) / den;
+    if (t >= 0.001f && t <= *best_t) {
+      float P[3] = {o[0] + t * d[0], o[1] + t * d[1], o[2] + t * d[2]};
+      float w[3] = {P[0] - q[0], P[1] - q[1], P[2] - q[2]};
+      float wu = dot3f(w, q + 4), wv = dot3f(w, q + 8);
+      float uu = q[7], uv = q[11], vv = q[15];
+      float denom = uu * vv - uv * uv;
+      float s1 = vv * wu - uv * wv, t1 = uu * wv - uv * wu;
+      float s = s1 / denom, tb = t1 / denom;
+      if (!(s < 0 || tb < 0 || s + tb > 1)) {
+        int face = j->tri_face[k];
+        if (t < *best_t || (t == *best_t && face < *best_id)) { *best_t = t; *best_id = face; }
+      }
+    }
+  }
+}
+
 static void* bvh_worker(void* arg) {
   bvh_job* j = (bvh_job*)arg;
   uint32_t stack[64];
@@ -71,10 +94,11 @@ static void* bvh_worker(void* arg) {
       float iv[3];
       for (int k = 0; k < 3; ++k) { iv[k] = 1.0f / d[k]; if (!(fabsf(iv[k]) <= 1e18f)) iv[k] = copysignf(1e18f, d[k]); }
       float oi[3] = {o[0] * iv[0], o[1] * iv[1], o[2] * iv[2]};
+      for (uint32_t k = j->ntris - j->nwild; k < j->ntris; ++k) { ++tt; tri_test(j, k, o, d, &best_t, &best_id); }
       const uint32_t* root = j->nodes;
       uint32_t cur = root[7] ? (LEAF_BIT | (root[7] << 28) | root[3]) : root[3];
       int sp = 0;
-      for (;;) {
+      if (j->nwild < j->ntris) for (;;) {
         if (!(cur & LEAF_BIT)) {
           const uint32_t* n0 = j->nodes + 8 * (size_t)cur;
           const uint32_t* n1 = n0 + 8;
@@ -96,28 +120,7 @@ static void* bvh_worker(void* arg) {
           if (h1) { cur = e1; continue; }
         } else {
           uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
-          for (uint32_t k = first; k < first + cnt; ++k) {
-            const float* q = j->tris + 16 * (size_t)k;
-            ++tt;
-            const float* nrm = q + 12;
-            float den = dot3f(nrm, d);
-            if (den != 0.0f) {
-              float t = (q[3] - dot3f(o, nrm)) / den;
-              if (t >= 0.001f && t <= best_t) {
-                float P[3] = {o[0] + t * d[0], o[1] + t * d[1], o[2] + t * d[2]};
-                float w[3] = {P[0] - q[0], P[1] - q[1], P[2] - q[2]};
-                float wu = dot3f(w, q + 4), wv = dot3f(w, q + 8);
-                float uu = q[7], uv = q[11], vv = q[15];
-                float denom = uu * vv - uv * uv;
-                float s1 = vv * wu - uv * wv, t1 = uu * wv - uv * wu;
-                float s = s1 / denom, tb = t1 / denom;
-                if (!(s < 0 || tb < 0 || s + tb > 1)) {
-                  int face = j->tri_face[k];
-                  if (t < best_t || (t == best_t && face < best_id)) { best_t = t; best_id = face; }
-                }
-              }
-            }
-          }
+          for (uint32_t k = first; k < first + cnt; ++k) { ++tt; tri_test(j, k, o, d, &best_t, &best_id); }
         }
         if (sp == 0) break;
         cur = stack[--sp];
@@ -131,7 +134,7 @@ static void* bvh_worker(void* arg) {
 }
 
 /* d1 = the direction a Ray object holds (already normalised once); triangles only, no spheres. */
-void ora_bvh_trace(const uint32_t* nodes8, const float* tri16, const int32_t* tri_face, uint32_t ntris,
+void ora_bvh_trace(const uint32_t* nodes8, const float* tri16, const int32_t* tri_face, uint32_t ntris, uint32_t nwild,
                    const float* root_lo, const float* root_hi, const float* o, const float* d1, int n, int threads,
                    float* t, int32_t* face, uint32_t* nodes_visited, uint32_t* tris_tested) {
   if (threads < 1) threads = 1;
@@ -140,7 +143,7 @@ void ora_bvh_trace(const uint32_t* nodes8, const float* tri16, const int32_t* tr
   pthread_t th[256];
   for (int i = 0; i < threads; ++i) {
     bvh_job* j = &jobs[i];
-    j->nodes = nodes8; j->tris = tri16; j->tri_face = tri_face; j->ntris = ntris; j->root_lo = root_lo; j->root_hi = root_hi;
+    j->nodes = nodes8; j->tris = tri16; j->tri_face = tri_face; j->ntris = ntris; j->nwild = nwild; j->root_lo = root_lo; j->root_hi = root_hi;
     j->o = o; j->d1 = d1; j->n = n; j->tid = i; j->nthreads = threads; j->t = t; j->face = face;
     j->nodes_visited = nodes_visited; j->tris_tested = tris_tested;
   }

@@ -34,13 +34,14 @@ class Rect(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_reflection", C.c_uint64),
                 ("rays_refraction", C.c_uint64), ("rays_gi", C.c_uint64), ("ms_trace", C.c_float),
-                ("ms_total", C.c_float), ("launches_trace", C.c_uint32), ("reserved", C.c_uint32)]
+                ("ms_total", C.c_float), ("launches_trace", C.c_uint32), ("ms_trace_camera", C.c_float)]
 
 
 class SceneInfo(C.Structure):
     _fields_ = [("ntris", C.c_uint32), ("nverts", C.c_uint32), ("nnodes", C.c_uint32), ("nleaves", C.c_uint32),
                 ("max_depth", C.c_uint32), ("nspheres", C.c_uint32), ("nlights", C.c_uint32),
-                ("nmaterials", C.c_uint32), ("device_bytes", C.c_uint64), ("build_ms", C.c_float)]
+                ("nmaterials", C.c_uint32), ("device_bytes", C.c_uint64), ("build_ms", C.c_float),
+                ("nwild", C.c_uint32)]
 
 
 # every symbol include/rtx.h declares
@@ -48,7 +49,8 @@ SYMBOLS = ["rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_
            "rtx_scene_add_material", "rtx_scene_set_spheres", "rtx_scene_set_lights", "rtx_scene_build", "rtx_scene_commit",
            "rtx_scene_get_tris",
            "rtx_scene_get_info", "rtx_scene_get_bvh", "rtx_trace_closest", "rtx_trace_closest_dev",
-           "rtx_trace_visible", "rtx_render", "rtx_render_dev", "rtx_get_stats"]
+           "rtx_trace_visible", "rtx_render", "rtx_render_dev", "rtx_tiles_count", "rtx_render_tiles_dev",
+           "rtx_get_stats"]
 
 _lib = None
 
@@ -83,6 +85,9 @@ def lib():
         L.rtx_render_dev.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Options), Rect, C.c_void_p,
                                      C.c_void_p, C.c_void_p]
         L.rtx_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.rtx_tiles_count.argtypes = [Rect, C.c_int32, C.c_int32, C.c_int32]
+        L.rtx_render_tiles_dev.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Options), Rect, C.c_int32,
+                                           C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -114,6 +119,11 @@ def make_camera(view34, width, height, fovy=60.0, aspect=None, subpixel=(0.0, 0.
 
 def fp(a):
     return a.ctypes.data_as(_f)
+
+
+def tiles_count(rect, tile_size, part, nparts):
+    x0, y0, x1, y1 = rect
+    return _check(lib().rtx_tiles_count(Rect(x0, y0, x1, y1), tile_size, part, nparts))
 
 
 class Scene:
@@ -221,6 +231,11 @@ class Scene:
         x0, y0, x1, y1 = rect
         _check(lib().rtx_render_dev(self.h, C.byref(cam), C.byref(opts), Rect(x0, y0, x1, y1), rgb_ptr, t_ptr,
                                     face_ptr))
+
+    def render_tiles_dev(self, cam, opts, rect, tile_size, part, nparts, rgb_ptr, t_ptr, face_ptr):
+        x0, y0, x1, y1 = rect
+        _check(lib().rtx_render_tiles_dev(self.h, C.byref(cam), C.byref(opts), Rect(x0, y0, x1, y1), tile_size, part,
+                                          nparts, rgb_ptr, t_ptr, face_ptr))
 
     def stats(self):
         s = Stats()

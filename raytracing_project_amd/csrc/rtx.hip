@@ -76,6 +76,7 @@ struct rtx_scene {
   std::vector<float4> h_tri_leaf, h_face_nm;
   std::vector<int32_t> h_tri_face;
   float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
+  uint32_t nwild = 0;
   // committed state
   bool committed = false;
   int device = -1;
@@ -87,6 +88,7 @@ struct rtx_scene {
   DevBuf w_rays[2], w_hits[2], w_parents, w_shadow_rays, w_shadow_hits, w_counters, w_io[6];
   EventPool events;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_spans, all_spans;
+  size_t camera_span = (size_t)-1;   // index into trace_spans of the k_trace_camera launch
   rtx_stats stats{};
   rtx_scene_info info{};
   int ncu = 256;
@@ -176,7 +178,9 @@ extern "C" int rtx_scene_build(rtx_scene* s) {
   std::vector<float4> tri_rec((size_t)ntris * 4);        // mesh order first, permuted below
   std::vector<float4>& face_nm = s->h_face_nm;
   face_nm.assign(std::max<uint32_t>(ntris, 1), make_float4(0, 0, 0, 0));
-  std::vector<float> lo((size_t)ntris * 3), hi((size_t)ntris * 3);
+  std::vector<float> lo, hi;               // padded boxes of the triangles that go into the BVH
+  std::vector<uint32_t> regular, wild;     // mesh face ids
+  lo.reserve((size_t)ntris * 3); hi.reserve((size_t)ntris * 3);
   float scene_abs = 0.0f;
   for (size_t i = 0; i < s->verts.size(); ++i) scene_abs = std::max(scene_abs, std::fabs(s->verts[i]));
   const float pad_abs = std::max(2e-5f * scene_abs, 1e-30f);
@@ -195,22 +199,43 @@ extern "C" int rtx_scene_build(rtx_scene* s) {
     int32_t m = s->tri_mat[f];
     float mw; std::memcpy(&mw, &m, 4);
     face_nm[f] = make_float4(nq.x, nq.y, nq.z, mw);
-    // padded culling box: the reference accepts hit points a little outside the exact
-    // triangle (fp32 barycentrics, worse for slivers), so boxes get an absolute and a
-    // size-relative margin; see DESIGN.md "conservative boxes".
+    // Conservative culling box.  The reference's isInTriangle (src/Intersect.cpp:24-46) works
+    // on fp32 barycentrics; with q = sin^2(angle at v0) its denominator carries a relative
+    // error of ~15 eps / q and its numerators ~16 eps |w| |u| |v|^2, so the set of points it
+    // accepts reaches outside the exact triangle by about
+    //     40 eps / sqrt(q) * (1 + (|u| + |v|) / |v2 - v1|) * (longest edge).
+    // Boxes are padded by that plus margins for the plane-distance and slab rounding.  Below
+    // q = 1e-5 the denominator's sign is no longer trustworthy and the accepted set is
+    // unbounded: such triangles stay out of the hierarchy and are tested by every ray
+    // ("wild" list), which is what the reference's brute-force scan does for all of them.
+    const double du[3] = {(double)b.x - a.x, (double)b.y - a.y, (double)b.z - a.z};
+    const double dv[3] = {(double)c.x - a.x, (double)c.y - a.y, (double)c.z - a.z};
+    const double de[3] = {dv[0] - du[0], dv[1] - du[1], dv[2] - du[2]};
+    const double duu = du[0] * du[0] + du[1] * du[1] + du[2] * du[2], dvv = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
+    const double duv = du[0] * dv[0] + du[1] * dv[1] + du[2] * dv[2];
+    const double dee = de[0] * de[0] + de[1] * de[1] + de[2] * de[2];
+    const double q = (duu * dvv > 0) ? (duu * dvv - duv * duv) / (duu * dvv) : 0.0;
+    const bool finite_rec = std::isfinite(D) && std::isfinite(uu) && std::isfinite(vv) && std::isfinite(nq.x + nq.y + nq.z);
+    if (!(q >= 1e-5) || !(dee > 0) || !finite_rec) { wild.push_back(f); continue; }
+    const double lu = std::sqrt(duu), lv = std::sqrt(dvv), le = std::sqrt(dee);
+    const double longest = std::max(lu, std::max(lv, le));
+    const double fuzz = 3e-6 / std::sqrt(q) * (1.0 + (lu + lv) / le);
+    const float pad = pad_abs + (float)(longest * (2e-3 + fuzz));
     const float pa[3] = {a.x, a.y, a.z}, pb[3] = {b.x, b.y, b.z}, pc[3] = {c.x, c.y, c.z};
-    float ext = 0.0f;
+    float bl[3], bh[3];
     for (int k = 0; k < 3; ++k) {
-      float mn = std::min(pa[k], std::min(pb[k], pc[k])), mx = std::max(pa[k], std::max(pb[k], pc[k]));
-      lo[3 * (size_t)f + k] = mn; hi[3 * (size_t)f + k] = mx;
-      ext = std::max(ext, mx - mn);
+      bl[k] = std::min(pa[k], std::min(pb[k], pc[k])); bh[k] = std::max(pa[k], std::max(pb[k], pc[k]));
     }
-    const float pad = pad_abs + 2e-3f * ext;
-    for (int k = 0; k < 3; ++k) { lo[3 * (size_t)f + k] -= pad; hi[3 * (size_t)f + k] += pad; }
+    for (int k = 0; k < 3; ++k) { lo.push_back(bl[k] - pad); hi.push_back(bh[k] + pad); }
+    regular.push_back(f);
   }
-  // ---- BVH
+  // ---- BVH over the regular triangles; wild ones are appended after the leaf-ordered run
   int threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
-  build_bvh(lo.data(), hi.data(), ntris, threads, &s->bvh);
+  const uint32_t nreg = (uint32_t)regular.size();
+  build_bvh(lo.data(), hi.data(), nreg, threads, &s->bvh);
+  for (uint32_t k = 0; k < nreg; ++k) s->bvh.order[k] = regular[s->bvh.order[k]];
+  s->bvh.order.insert(s->bvh.order.end(), wild.begin(), wild.end());
+  s->nwild = (uint32_t)wild.size();
   std::vector<float4>& tri_leaf = s->h_tri_leaf;
   std::vector<int32_t>& tri_face = s->h_tri_face;
   tri_leaf.assign((size_t)ntris * 4, make_float4(0, 0, 0, 0));
@@ -234,7 +259,7 @@ extern "C" int rtx_scene_build(rtx_scene* s) {
   rtx_scene_info& in = s->info;
   std::memset(&in, 0, sizeof in);
   in.ntris = ntris; in.nverts = nverts; in.nnodes = (uint32_t)s->bvh.nodes.size(); in.nleaves = s->bvh.nleaves;
-  in.max_depth = s->bvh.max_depth;
+  in.max_depth = s->bvh.max_depth; in.nwild = s->nwild;
   in.build_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
   if (s->bvh.max_depth + 2 > (uint32_t)kStackDepth) return fail(RTX_ELIMIT, "BVH depth %u exceeds the traversal stack", s->bvh.max_depth);
   s->built = true;
@@ -286,7 +311,7 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   d.nodes = s->d_nodes.as<float4>(); d.tris = s->d_tris.as<float4>(); d.tri_face = s->d_tri_face.as<int>();
   d.face_nm = s->d_face_nm.as<float4>(); d.spheres = s->d_spheres.as<float4>(); d.sph_mat = s->d_sph_mat.as<int>();
   d.mats = s->d_mats.as<DevMat>(); d.lights = s->d_lights.as<float4>();
-  d.ntris = ntris; d.nspheres = (uint32_t)(s->spheres.size() / 4); d.nlights = (uint32_t)(s->lights.size() / 3);
+  d.ntris = ntris; d.nwild = s->nwild; d.nspheres = (uint32_t)(s->spheres.size() / 4); d.nlights = (uint32_t)(s->lights.size() / 3);
   d.nmats = (uint32_t)s->mats.size();
   for (int k = 0; k < 3; ++k) { d.root_lo[k] = s->root_lo[k]; d.root_hi[k] = s->root_hi[k]; }
   const BvhNode& root = s->bvh.nodes[0];
@@ -336,7 +361,7 @@ static void span_end(rtx_scene* s, bool trace) {
   (void)hipEventRecord((trace ? s->trace_spans : s->all_spans).back().second, s->stream);
 }
 static void stats_begin(rtx_scene* s) {
-  s->events.reset(); s->trace_spans.clear(); s->all_spans.clear();
+  s->events.reset(); s->trace_spans.clear(); s->all_spans.clear(); s->camera_span = (size_t)-1;
   std::memset(&s->stats, 0, sizeof s->stats);
   span_begin(s, false);
 }
@@ -345,7 +370,12 @@ static int stats_end(rtx_scene* s) {
   HIP_TRY(hipStreamSynchronize(s->stream));
   HIP_TRY(hipGetLastError());
   float ms = 0;
-  for (auto& sp : s->trace_spans) { float m = 0; (void)hipEventElapsedTime(&m, sp.first, sp.second); ms += m; }
+  for (size_t i = 0; i < s->trace_spans.size(); ++i) {
+    float m = 0;
+    (void)hipEventElapsedTime(&m, s->trace_spans[i].first, s->trace_spans[i].second);
+    ms += m;
+    if (i == s->camera_span) s->stats.ms_trace_camera = m;
+  }
   s->stats.ms_trace = ms;
   s->stats.launches_trace = (uint32_t)s->trace_spans.size();
   float tot = 0;
@@ -472,20 +502,61 @@ static int make_camera(const rtx_camera* cam, rtx_rect r, DevCamera* C) {
   C->scale = scale;
   C->sub[0] = cam->subpixel[0]; C->sub[1] = cam->subpixel[1];
   C->x0 = r.x0; C->y0 = r.y0; C->w = r.x1 - r.x0; C->h = r.y1 - r.y0;
+  C->ts = 0; C->part = 0; C->nparts = 1; C->tiles_x = 0; C->ntiles_local = 0; C->pad_ = 0;
+  return RTX_OK;
+}
+
+static int render_impl(rtx_scene* s, const DevCamera& C, uint32_t npix, uint32_t nblocks, const rtx_options* opt,
+                       float* rgb, float* t, int32_t* face);
+
+static int check_render_args(rtx_scene* s, const rtx_camera* cam, const rtx_options* opt, const float* rgb) {
+  if (!cam || !opt) return fail(RTX_EINVAL, "null camera/options");
+  if (opt->refraction || opt->gi_rays) return fail(RTX_EINVAL, "refraction / gi_rays are not implemented on the GPU path yet");
+  if (opt->max_bounces < 0 || opt->max_bounces > 16) return fail(RTX_ELIMIT, "max_bounces must be in [0,16]");
+  if (!s->slights.empty() && rgb) return fail(RTX_EINVAL, "spherical lights are not implemented on the GPU path yet");
+  if (rgb && s->dev.nlights == 0) return fail(RTX_EINVAL, "shading needs at least one light (the reference divides by the light count)");
   return RTX_OK;
 }
 
 extern "C" int rtx_render_dev(rtx_scene* s, const rtx_camera* cam, const rtx_options* opt, rtx_rect rect, float* rgb,
                               float* t, int32_t* face) {
   if (int rc = check_ready(s)) return rc;
-  if (!cam || !opt) return fail(RTX_EINVAL, "null camera/options");
-  if (opt->refraction || opt->gi_rays) return fail(RTX_EINVAL, "refraction / gi_rays are not implemented on the GPU path yet");
-  if (opt->max_bounces < 0 || opt->max_bounces > 16) return fail(RTX_ELIMIT, "max_bounces must be in [0,16]");
-  if (!s->slights.empty() && rgb) return fail(RTX_EINVAL, "spherical lights are not implemented on the GPU path yet");
-  if (rgb && s->dev.nlights == 0) return fail(RTX_EINVAL, "shading needs at least one light (the reference divides by the light count)");
+  if (int rc = check_render_args(s, cam, opt, rgb)) return rc;
   DevCamera C;
   if (int rc = make_camera(cam, rect, &C)) return rc;
   const uint32_t npix = (uint32_t)C.w * (uint32_t)C.h;
+  const uint32_t tiles = (uint32_t)((C.w + 15) / 16) * (uint32_t)((C.h + 15) / 16);
+  return render_impl(s, C, npix, tiles, opt, rgb, t, face);
+}
+
+extern "C" int rtx_tiles_count(rtx_rect rect, int32_t tile_size, int32_t part, int32_t nparts) {
+  if (rect.x1 <= rect.x0 || rect.y1 <= rect.y0) return fail(RTX_EINVAL, "empty rectangle");
+  if (tile_size < 16 || tile_size > 1024 || (tile_size & 15)) return fail(RTX_EINVAL, "tile_size must be a multiple of 16 in [16,1024]");
+  if (nparts < 1 || part < 0 || part >= nparts) return fail(RTX_EINVAL, "need 0 <= part < nparts");
+  const int64_t tx = (rect.x1 - rect.x0 + tile_size - 1) / tile_size, ty = (rect.y1 - rect.y0 + tile_size - 1) / tile_size;
+  const int64_t total = tx * ty;
+  return (int)((total - part + nparts - 1) / nparts);
+}
+
+extern "C" int rtx_render_tiles_dev(rtx_scene* s, const rtx_camera* cam, const rtx_options* opt, rtx_rect rect,
+                                    int32_t tile_size, int32_t part, int32_t nparts, float* rgb, float* t, int32_t* face) {
+  if (int rc = check_ready(s)) return rc;
+  if (int rc = check_render_args(s, cam, opt, rgb)) return rc;
+  const int nt = rtx_tiles_count(rect, tile_size, part, nparts);
+  if (nt < 0) return nt;
+  DevCamera C;
+  if (int rc = make_camera(cam, rect, &C)) return rc;
+  if (nt == 0) return RTX_OK;
+  if ((int64_t)nt * tile_size * tile_size >= (1ll << 31)) return fail(RTX_ELIMIT, "too many pixels in this part");
+  C.ts = tile_size; C.part = part; C.nparts = nparts; C.tiles_x = (C.w + tile_size - 1) / tile_size;
+  C.ntiles_local = (uint32_t)nt;
+  const uint32_t npix = (uint32_t)nt * (uint32_t)(tile_size * tile_size);
+  const uint32_t nblocks = (uint32_t)nt * (uint32_t)((tile_size / 16) * (tile_size / 16));
+  return render_impl(s, C, npix, nblocks, opt, rgb, t, face);
+}
+
+static int render_impl(rtx_scene* s, const DevCamera& C, uint32_t npix, uint32_t tiles, const rtx_options* opt,
+                       float* rgb, float* t, int32_t* face) {
   const uint32_t NL = s->dev.nlights;
   const bool shade = rgb != nullptr;
   if (int rc = s->w_hits[0].ensure((size_t)npix * 8)) return rc;
@@ -509,8 +580,8 @@ extern "C" int rtx_render_dev(rtx_scene* s, const rtx_camera* cam, const rtx_opt
   HIP_TRY(hipMemsetAsync(s->w_counters.p, 0, (size_t)(max_gen + 2) * 16, s->stream));
   uint32_t* cnt = s->w_counters.as<uint32_t>();
 
-  const uint32_t tiles = (uint32_t)((C.w + 15) / 16) * (uint32_t)((C.h + 15) / 16);
   span_begin(s, true);
+  s->camera_span = s->trace_spans.size() - 1;
   hipLaunchKernelGGL(k_trace_camera, dim3(std::min<uint32_t>(tiles, (uint32_t)s->ncu * 64)), dim3(kBlock), 0, s->stream, s->dev, C,
                      tiles, s->w_hits[0].as<uint2>());
   span_end(s, true);
@@ -552,7 +623,18 @@ extern "C" int rtx_render_dev(rtx_scene* s, const rtx_camera* cam, const rtx_opt
   std::vector<uint32_t> hc((size_t)(max_gen + 2) * 4);
   HIP_TRY(hipMemcpyAsync(hc.data(), s->w_counters.p, hc.size() * 4, hipMemcpyDeviceToHost, s->stream));
   if (int rc = stats_end(s)) return rc;
-  s->stats.rays_primary = npix;
+  uint64_t live = npix;
+  if (C.ts) {   // partial edge tiles: count only slots that are pixels of the rectangle
+    live = 0;
+    const int tiles_y = (C.h + C.ts - 1) / C.ts;
+    for (uint32_t k = 0; k < C.ntiles_local; ++k) {
+      const uint32_t g = k * (uint32_t)C.nparts + (uint32_t)C.part;
+      const int gx = (int)(g % (uint32_t)C.tiles_x), gy = (int)(g / (uint32_t)C.tiles_x);
+      if (gy >= tiles_y) continue;
+      live += (uint64_t)std::min(C.ts, C.w - gx * C.ts) * (uint64_t)std::min(C.ts, C.h - gy * C.ts);
+    }
+  }
+  s->stats.rays_primary = live;
   if (shade) {
     for (int g = 0; g <= max_gen; ++g) {
       if (opt->shadows) s->stats.rays_shadow += (uint64_t)hc[4 * g] * NL;

@@ -33,7 +33,7 @@ struct DevScene {
   uint32_t ntris, nspheres, nlights, nmats;
   float root_lo[3], root_hi[3];   // Box(mesh) of the reference, used as its root gate
   uint32_t root_entry;            // traversal entry of the BVH root
-  uint32_t pad;
+  uint32_t nwild;                 // ill-conditioned triangles [ntris - nwild, ntris): tested by every ray
 };
 
 struct DevCamera {
@@ -44,9 +44,14 @@ struct DevCamera {
   float scale;         // 1 / getPerspectiveScale
   float sub[2];
   int x0, y0, w, h;    // pixel rectangle
+  // Tiled-compact layout (multi-GPU image partition): the rectangle is cut into ts x ts
+  // tiles, this scene renders tiles part, part + nparts, ... and stores local tile k at
+  // compact pixels [k*ts*ts, (k+1)*ts*ts), row-major inside the tile.  ts == 0: plain
+  // row-major rectangle.
+  int ts, part, nparts, tiles_x;
+  uint32_t ntiles_local, pad_;
 };
 
-struct Hit { float t; int id; };   // id >= 0 mesh face, -1 miss, <= -2 sphere (-2 - index)
 
 // ---------------------------------------------------------------- reference primitives
 // Intersect::BoxObject::intersects (src/Intersect.cpp:67-145); used only for the root gate.
@@ -91,9 +96,42 @@ __device__ __forceinline__ float ref_sphere_t(V3 o, V3 d, float4 s) {
   return INFINITY;
 }
 
+struct Hit { float t; int id; };   // id >= 0 mesh face, -1 miss, <= -2 sphere (-2 - index)
+
 __device__ __forceinline__ float cull_inv(float d) {
   const float iv = 1.0f / d;
   return (fabsf(iv) <= 1e18f) ? iv : copysignf(1e18f, d);
+}
+
+// Intersect::Triangle::intersects + isInTriangle (src/Intersect.cpp:6-46) on leaf-ordered
+// triangle k; u, v, u.u, u.v, v.v, n.v0 are ray independent and were hoisted into the record.
+// Updates `best` with the reference's reduction: strict < over faces in mesh order, i.e. the
+// lexicographic min of (t, face); a sphere at the same t keeps winning (src/flyscene.cpp:569).
+__device__ __forceinline__ void test_triangle(const DevScene& S, uint32_t k, V3 o, V3 d, Hit* best) {
+  const float4 q3 = S.tris[4 * k + 3];             // n, vv
+  const float4 q0 = S.tris[4 * k];                 // v0, D
+  const V3 n = v3(q3.x, q3.y, q3.z);
+  const float den = dot(n, d);
+  if (den != 0.0f) {
+    const float t = (q0.w - dot(o, n)) / den;
+    if (t >= kPrecision && t <= best->t) {
+      const float4 q1 = S.tris[4 * k + 1];         // u, uu
+      const float4 q2 = S.tris[4 * k + 2];         // v, uv
+      const V3 P = point_on_ray(o, d, t);
+      const V3 w = P - v3(q0.x, q0.y, q0.z);
+      const float wu = dot(w, v3(q1.x, q1.y, q1.z)), wv = dot(w, v3(q2.x, q2.y, q2.z));
+      const float uu = q1.w, uv = q2.w, vv = q3.w;
+      const float denom = uu * vv - uv * uv;
+      const float s1 = vv * wu - uv * wv;
+      const float t1 = uu * wv - uv * wu;
+      const float s = s1 / denom;
+      const float tt = t1 / denom;
+      if (!(s < 0 || tt < 0 || s + tt > 1)) {
+        const int face = S.tri_face[k];
+        if (t < best->t || (t == best->t && face < best->id)) { best->t = t; best->id = face; }
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------- closest hit
@@ -116,6 +154,9 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& S, V3 o, V3 d1, uint3
   // right sign instead of inf - inf = NaN in the fused form below.
   const float ivx = cull_inv(d.x), ivy = cull_inv(d.y), ivz = cull_inv(d.z);
   const float oix = o.x * ivx, oiy = o.y * ivy, oiz = o.z * ivz;
+
+  for (uint32_t k = S.ntris - S.nwild; k < S.ntris; ++k) test_triangle(S, k, o, d, &best);
+  if (S.nwild == S.ntris) return best;
 
   uint32_t cur = S.root_entry;
   int sp = 0;
@@ -155,36 +196,7 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& S, V3 o, V3 d1, uint3
       if (h1) { cur = e1; continue; }
     } else {
       const uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
-      for (uint32_t k = first; k < first + cnt; ++k) {
-        // Intersect::Triangle::intersects (src/Intersect.cpp:6-23)
-        const float4 q3 = S.tris[4 * k + 3];             // n, vv
-        const float4 q0 = S.tris[4 * k];                 // v0, D
-        const V3 n = v3(q3.x, q3.y, q3.z);
-        const float den = dot(n, d);
-        if (den != 0.0f) {
-          const float t = (q0.w - dot(o, n)) / den;
-          if (t >= kPrecision && t <= best.t) {
-            const float4 q1 = S.tris[4 * k + 1];         // u, uu
-            const float4 q2 = S.tris[4 * k + 2];         // v, uv
-            const V3 P = point_on_ray(o, d, t);
-            // isInTriangle (src/Intersect.cpp:24-46); u, v, uu, uv, vv are ray independent
-            const V3 w = P - v3(q0.x, q0.y, q0.z);
-            const float wu = dot(w, v3(q1.x, q1.y, q1.z)), wv = dot(w, v3(q2.x, q2.y, q2.z));
-            const float uu = q1.w, uv = q2.w, vv = q3.w;
-            const float denom = uu * vv - uv * uv;
-            const float s1 = vv * wu - uv * wv;
-            const float t1 = uu * wv - uv * wu;
-            const float s = s1 / denom;
-            const float tt = t1 / denom;
-            if (!(s < 0 || tt < 0 || s + tt > 1)) {
-              const int face = S.tri_face[k];
-              // strict < over faces in mesh order == lexicographic min of (t, face);
-              // a sphere at the same t keeps winning (src/flyscene.cpp:569, best.id < 0)
-              if (t < best.t || (t == best.t && face < best.id)) { best.t = t; best.id = face; }
-            }
-          }
-        }
-      }
+      for (uint32_t k = first; k < first + cnt; ++k) test_triangle(S, k, o, d, &best);
     }
     if (sp == 0) break;
     --sp;
@@ -210,15 +222,36 @@ __device__ __forceinline__ void camera_ray(const DevCamera& C, int x, int y, V3*
   *o = org;
   *d1 = normalized(w - org);
 }
-// thread -> pixel of the rectangle: 16x16 tiles per block, 8x8 sub-tiles per wave
-__device__ __forceinline__ bool tile_pixel(const DevCamera& C, uint32_t block, uint32_t tid, int* px, int* py) {
-  const uint32_t tiles_x = (uint32_t)(C.w + 15) >> 4;
-  const uint32_t bx = block % tiles_x, by = block / tiles_x;
+// Output slot p -> pixel (x, y) relative to the rectangle; false for the dead slots of
+// partial edge tiles in the tiled-compact layout.
+__device__ __forceinline__ bool slot_pixel(const DevCamera& C, uint32_t p, int* px, int* py) {
+  if (C.ts == 0) { *px = (int)(p % (uint32_t)C.w); *py = (int)(p / (uint32_t)C.w); return true; }
+  const uint32_t tt = (uint32_t)(C.ts * C.ts);
+  const uint32_t k = p / tt, in = p % tt;
+  const uint32_t g = k * (uint32_t)C.nparts + (uint32_t)C.part;
+  const int x = (int)(g % (uint32_t)C.tiles_x) * C.ts + (int)(in % (uint32_t)C.ts);
+  const int y = (int)(g / (uint32_t)C.tiles_x) * C.ts + (int)(in / (uint32_t)C.ts);
+  *px = x; *py = y;
+  return x < C.w && y < C.h;
+}
+// (block, thread) -> output slot: a block covers 16x16 pixels, a wave an 8x8 sub-tile, so
+// that the 64 rays of a wave stay coherent.  Returns false where there is no pixel.
+__device__ __forceinline__ bool block_slot(const DevCamera& C, uint32_t block, uint32_t tid, uint32_t* slot, int* px, int* py) {
   const uint32_t wave = tid >> 6, lane = tid & 63;
-  const int lx = (int)(bx * 16 + (wave & 1) * 8 + (lane & 7));
-  const int ly = (int)(by * 16 + (wave >> 1) * 8 + (lane >> 3));
-  *px = lx; *py = ly;
-  return lx < C.w && ly < C.h;
+  const int ix = (int)((wave & 1) * 8 + (lane & 7)), iy = (int)((wave >> 1) * 8 + (lane >> 3));
+  if (C.ts == 0) {
+    const uint32_t bxn = (uint32_t)(C.w + 15) >> 4;
+    const int lx = (int)(block % bxn) * 16 + ix, ly = (int)(block / bxn) * 16 + iy;
+    *px = lx; *py = ly; *slot = (uint32_t)ly * (uint32_t)C.w + (uint32_t)lx;
+    return lx < C.w && ly < C.h;
+  }
+  const uint32_t sub_n = (uint32_t)(C.ts >> 4);                 // 16x16 blocks per tile side
+  const uint32_t k = block / (sub_n * sub_n), sb = block % (sub_n * sub_n);
+  const int tx = (int)(sb % sub_n) * 16 + ix, ty = (int)(sb / sub_n) * 16 + iy;
+  const uint32_t g = k * (uint32_t)C.nparts + (uint32_t)C.part;
+  const int x = (int)(g % (uint32_t)C.tiles_x) * C.ts + tx, y = (int)(g / (uint32_t)C.tiles_x) * C.ts + ty;
+  *px = x; *py = y; *slot = k * (uint32_t)(C.ts * C.ts) + (uint32_t)(ty * C.ts + tx);
+  return x < C.w && y < C.h;
 }
 
 // ---------------------------------------------------------------- kernels
@@ -226,12 +259,12 @@ __device__ __forceinline__ bool tile_pixel(const DevCamera& C, uint32_t block, u
 __global__ __launch_bounds__(kBlock) void k_trace_camera(DevScene S, DevCamera C, uint32_t nblocks, uint2* hits) {
   __shared__ uint32_t stack[kStackDepth * kBlock];
   for (uint32_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-    int lx, ly;
-    if (!tile_pixel(C, blk, threadIdx.x, &lx, &ly)) continue;
+    int lx, ly; uint32_t slot;
+    if (!block_slot(C, blk, threadIdx.x, &slot, &lx, &ly)) continue;
     V3 o, d1;
     camera_ray(C, C.x0 + lx, C.y0 + ly, &o, &d1);
     const Hit h = closest_hit(S, o, d1, stack + threadIdx.x);
-    hits[(size_t)ly * C.w + lx] = make_uint2(__float_as_uint(h.t), (uint32_t)h.id);
+    hits[slot] = make_uint2(__float_as_uint(h.t), (uint32_t)h.id);
   }
 }
 
@@ -312,9 +345,11 @@ struct RayRec { V3 o, d1; uint32_t pixel; float thr; bool valid; };
 __device__ __forceinline__ RayRec load_ray(int gen, const DevCamera& C, const float4* rays, uint32_t i) {
   RayRec r;
   if (gen == 0) {
-    const int x = (int)(i % (uint32_t)C.w), y = (int)(i / (uint32_t)C.w);
+    int x, y;
+    r.valid = slot_pixel(C, i, &x, &y);
     camera_ray(C, C.x0 + x, C.y0 + y, &r.o, &r.d1);
     r.pixel = i; r.thr = 1.0f;
+    return r;
   } else {
     const float4 ro = rays[2 * (size_t)i], rd = rays[2 * (size_t)i + 1];
     r.o = v3(ro.x, ro.y, ro.z); r.d1 = v3(rd.x, rd.y, rd.z);
@@ -376,15 +411,15 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs A) {
     float ht = INFINITY; int id = -1;
     if (live) {
       r = load_ray(A.gen, A.C, A.rays, i);
-      const uint2 h = A.hits[i];
+      const uint2 h = r.valid ? A.hits[i] : make_uint2(__float_as_uint(INFINITY), 0xFFFFFFFFu);
       ht = __uint_as_float(h.x); id = (int)h.y;
-      if (A.gen == 0) {
+      if (A.gen == 0 && r.valid) {
         if (A.out_t) A.out_t[i] = ht;
         if (A.out_face) A.out_face[i] = id >= 0 ? id : -1;
       }
     }
     const bool is_hit = live && (id != -1);
-    if (live && !is_hit && A.gen == 0 && A.rgb) {
+    if (live && r.valid && !is_hit && A.gen == 0 && A.rgb) {
       A.rgb[3 * (size_t)r.pixel] = (float)0.69019607843; A.rgb[3 * (size_t)r.pixel + 1] = 1.0f; A.rgb[3 * (size_t)r.pixel + 2] = 1.0f;
     }
     if (!A.rgb) continue;   // hits only

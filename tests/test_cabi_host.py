@@ -58,10 +58,13 @@ def test_argument_validation(api):
     assert L.rtx_scene_destroy(None) == 0
 
 
-def _check_bvh(nodes, order, ntris):
+def _check_bvh(nodes, order, ntris, nwild=0):
+    """Every triangle is either in exactly one leaf or in the trailing 'wild' run."""
     f = nodes.view(np.float32)
     assert sorted(order.tolist()) == list(range(ntris))
-    seen = np.zeros(ntris, bool)
+    seen = np.zeros(ntris - nwild, bool)
+    if ntris == nwild:
+        return 0
     stack = [(0, 0)]
     maxd = 0
     while stack:
@@ -88,7 +91,7 @@ def test_host_bvh_equals_bruteforce_on_bundled_scenes(api, oa, name):
     info = s.info()
     nodes, order = s.bvh()
     tris = s.tris()
-    assert _check_bvh(nodes, order, info.ntris) == info.max_depth <= 30
+    assert _check_bvh(nodes, order, info.ntris, info.nwild) == info.max_depth <= 30
     # leaf boxes contain their triangles
     os_ = oa.Scene(fx["verts"], fx["idx"], fx["tri_mat"], oracle_materials(fx["mats"]))
     lo, hi = os_.root_box()
@@ -96,7 +99,7 @@ def test_host_bvh_equals_bruteforce_on_bundled_scenes(api, oa, name):
     for cname in ("default", "oblique", "top"):
         cam = oa.make_camera(fx["view_" + cname], res, res)
         o, d1 = oa.camera_rays(cam, (0, 0, res, res))
-        t, face, nv, tt = oa.bvh_trace(nodes, tris, order, lo, hi, o, d1, threads=4)
+        t, face, nv, tt = oa.bvh_trace(nodes, tris, order, lo, hi, o, d1, threads=4, nwild=info.nwild)
         assert np.array_equal(face.reshape(res, res), fx["face_" + cname]), cname
         assert_bits_equal(t.reshape(res, res), fx["t_" + cname], "t " + cname)
         if info.ntris > 1000:
@@ -110,7 +113,8 @@ def test_host_bvh_equals_bruteforce_on_soup_and_random_rays(api, oa):
     s.build()
     nodes, order = s.bvh()
     tris = s.tris()
-    _check_bvh(nodes, order, 30000)
+    nwild = s.info().nwild
+    _check_bvh(nodes, order, 30000, nwild)
     os_ = oa.Scene(verts, idx, None, [oa.make_mtl()])
     lo, hi = os_.root_box()
     rng = np.random.default_rng(3)
@@ -125,7 +129,7 @@ def test_host_bvh_equals_bruteforce_on_soup_and_random_rays(api, oa):
     oo = np.zeros(3, np.float32)
     for i in range(n):
         oa.lib().ora_ray(oa.fp(o[i]), oa.fp(d[i]), oa.fp(oo), oa.fp(d1[i]))
-    t, face, nv, tt = oa.bvh_trace(nodes, tris, order, lo, hi, o, d1, threads=8)
+    t, face, nv, tt = oa.bvh_trace(nodes, tris, order, lo, hi, o, d1, threads=8, nwild=nwild)
     assert (brute["face"] >= 0).sum() > 500
     assert np.array_equal(face, brute["face"])
     assert_bits_equal(t, brute["t"], "t")
@@ -139,4 +143,5 @@ def test_empty_and_degenerate_scenes_build(api):
     s = api.Scene(v, [[0, 1, 2], [0, 0, 3], [0, 1, 2]], None, [])
     s.build()
     nodes, order = s.bvh()
-    _check_bvh(nodes, order, 3)
+    assert s.info().nwild == 3          # zero-area faces never enter the hierarchy
+    _check_bvh(nodes, order, 3, 3)

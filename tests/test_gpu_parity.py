@@ -249,3 +249,35 @@ def test_full_size_soup_1m_properties(api, oa):
         assert_bits_equal(t2, t[y0:y1, x0:x1], "t tile")
         assert_bits_equal(r2, rgb[y0:y1, x0:x1], "rgb tile")
     s.close()
+
+
+def test_tiled_compact_layout_equals_full_frame(api):
+    """rtx_render_tiles_dev (the per-rank call of the multi-GPU bench) reassembles to the
+    full frame bit-for-bit for 1, 2 and 3 parts, including partial edge tiles."""
+    import torch
+    from raytracing_project_amd import tiles
+    fx = load_scene_fixture("spheres")
+    s = make_scene(api, fx)
+    W, H, ts = 150, 83, 32
+    cam = api.make_camera(fx["view_oblique"], W, H)
+    opts = ns_options(api)
+    full_rgb, full_t, full_face = s.render(cam, opts, (0, 0, W, H))
+    for nparts in (1, 2, 3):
+        kmax = tiles.max_local_tiles(W, H, ts, nparts)
+        parts_rgb, parts_face, parts_t, prim = [], [], [], 0
+        for p in range(nparts):
+            rgb = torch.zeros((kmax * ts * ts, 3), dtype=torch.float32, device="cuda")
+            t = torch.full((kmax * ts * ts, 1), float("inf"), dtype=torch.float32, device="cuda")
+            face = torch.full((kmax * ts * ts, 1), -1, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            s.render_tiles_dev(cam, opts, (0, 0, W, H), ts, p, nparts, rgb.data_ptr(), t.data_ptr(), face.data_ptr())
+            prim += s.stats().rays_primary
+            parts_rgb.append(rgb); parts_t.append(t); parts_face.append(face)
+        assert prim == W * H
+        img = tiles.assemble(torch.stack(parts_rgb), W, H, ts, 3).cpu().numpy()
+        tt = tiles.assemble(torch.stack(parts_t), W, H, ts, 1).cpu().numpy()[..., 0]
+        ff = tiles.assemble(torch.stack(parts_face), W, H, ts, 1).cpu().numpy()[..., 0]
+        assert np.array_equal(ff, full_face)
+        assert_bits_equal(tt, full_t, "t")
+        assert_bits_equal(img, full_rgb, "rgb")
+    s.close()
