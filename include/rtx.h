@@ -50,8 +50,8 @@ typedef struct {
 
 /* Compile-time switches of the reference made run-time (src/flyscene.cpp:11,704 and the
  * unconditional reflect/refract/shadow calls at :686-723).  The reference itself is
- * {2, 1, 1, 8, 1, 0}.  refraction/gi_rays other than 0 are rejected by rtx_render until
- * the full calculateColor fidelity row lands. */
+ * {2, 1, 1, 8, 1, 0}.  gi_rays > 0 needs the reference leaf list
+ * (rtx_scene_build_reference_leafboxes), because trace_global_illum walks that list. */
 typedef struct {
   int32_t max_bounces;
   int32_t reflection;
@@ -99,7 +99,28 @@ int rtx_scene_set_spheres(rtx_scene*, const float* center_radius4, const int32_t
 /* Flyscene::lights / sphericalLights (src/flyscene.hpp:140-141, addLight :61-62). */
 int rtx_scene_set_lights(rtx_scene*, const float* xyz, uint32_t n, const float* sphere_xyzr, uint32_t m);
 
-/* Replaces Box(mesh) + divideBox_KD (src/box.h:41-85, src/flyscene.cpp:77-82,1110-1185).
+/* RTX_FLAG_NO_ROOT_GATE: closest-hit queries skip the root-AABB test that getIntersections
+ * performs before its triangle scan, which gives Flyscene::intersectTriangle(faces, o, d)
+ * semantics (src/flyscene.cpp:819-879) for a scene made of exactly that face list. */
+#define RTX_FLAG_NO_ROOT_GATE 1u
+int rtx_scene_set_flags(rtx_scene*, uint32_t flags);
+
+/* Flyscene::divideBox_KD + averagePoint / axisToDivide / isInBox and Box(mesh)
+ * (src/flyscene.cpp:974-993,1070-1185, src/box.h:41-85): the flat leaf list `boxes` that
+ * trace_global_illum (and the debug ray) walk; triangles are assigned by "any vertex inside"
+ * exactly as the reference does.  max_faces <= 0 means (int)sqrt(F + 100)
+ * (src/flyscene.cpp:79).  Returns the leaf count, or RTX_ELIMIT when the reference's split
+ * never terminates on this mesh (iter_cap <= 0 picks 64 F + 4096 queue pops).
+ * rtx_scene_set_leafboxes installs a caller-built list instead. */
+int rtx_scene_build_reference_leafboxes(rtx_scene*, int32_t max_faces, int64_t iter_cap);
+int rtx_scene_set_leafboxes(rtx_scene*, const float* bmin_xyz, const float* bmax_xyz, const uint32_t* start,
+                            const uint32_t* count, uint32_t nleaves, const int32_t* faces, uint32_t nfaces);
+/* Any output may be NULL; nleaves / nfaces receive the sizes. */
+int rtx_scene_get_leafboxes(const rtx_scene*, float* bmin_xyz, float* bmax_xyz, uint32_t* start, uint32_t* count,
+                            int32_t* faces, uint32_t* nleaves, uint32_t* nfaces);
+
+/* Replaces Box(mesh) + divideBox_KD as the acceleration structure of closest-hit queries
+ * (src/box.h:41-85, src/flyscene.cpp:77-82,517-585).
  * rtx_scene_build flattens the mesh into per-triangle records (reference arithmetic) and
  * builds the linear BVH on the host; it needs no GPU.  rtx_scene_commit builds if needed
  * and uploads everything to `device`. */
@@ -127,6 +148,20 @@ int rtx_trace_closest_dev(rtx_scene*, const float* origin_xyz, const float* dir_
  * blocker_material: material id the reference would return, -1 for the default Mtl. */
 int rtx_trace_visible(rtx_scene*, const float* light_xyz, const float* position_xyz, uint32_t n,
                       uint8_t* visible, int32_t* blocker_material);
+
+/* Tucano::Camera::screenToWorld for n raster positions (i,j pairs) and Camera::getCenter
+ * (dependencies/tucano/tucano/camera.hpp:115-118,155-173).  center may be NULL. */
+int rtx_camera_points(rtx_scene*, const rtx_camera*, const float* ij, uint32_t n, float* world_xyz, float* center_xyz);
+
+/* Flyscene::intersectBox(box, origin, dest) for n rays against one box (src/flyscene.cpp:906-972,
+ * src/Intersect.cpp:67-145): the slab-test t (may be negative), INFINITY on a miss. */
+int rtx_intersect_box(rtx_scene*, const float* bmin_xyz, const float* bmax_xyz, const float* origin_xyz,
+                      const float* dir_xyz, uint32_t n, float* t);
+
+/* Flyscene::traceRay(bounce, Ray(o,d), insideObject) for n rays (src/flyscene.cpp:587-601):
+ * the shaded colour, 3 floats per ray. */
+int rtx_trace_shade(rtx_scene*, const rtx_options*, const float* origin_xyz, const float* dir_xyz, uint32_t n,
+                    int32_t bounce, int32_t inside_object, float* rgb);
 
 /* Flyscene::updating_pixels / raytraceScene over a pixel rectangle
  * (src/flyscene.cpp:395-468): camera ray -> traceRay(0, ray, false) per pixel.

@@ -50,7 +50,8 @@ SYMBOLS = ["rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_
            "rtx_scene_get_tris",
            "rtx_scene_get_info", "rtx_scene_get_bvh", "rtx_trace_closest", "rtx_trace_closest_dev",
            "rtx_trace_visible", "rtx_render", "rtx_render_dev", "rtx_tiles_count", "rtx_render_tiles_dev",
-           "rtx_get_stats"]
+           "rtx_get_stats", "rtx_scene_build_reference_leafboxes", "rtx_scene_set_leafboxes",
+           "rtx_scene_get_leafboxes", "rtx_intersect_box", "rtx_trace_shade", "rtx_camera_points", "rtx_scene_set_flags"]
 
 _lib = None
 
@@ -85,6 +86,13 @@ def lib():
         L.rtx_render_dev.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Options), Rect, C.c_void_p,
                                      C.c_void_p, C.c_void_p]
         L.rtx_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.rtx_scene_build_reference_leafboxes.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
+        L.rtx_scene_set_leafboxes.argtypes = [C.c_void_p, _f, _f, _u, _u, C.c_uint32, _i, C.c_uint32]
+        L.rtx_scene_get_leafboxes.argtypes = [C.c_void_p, _f, _f, _u, _u, _i, _u, _u]
+        L.rtx_intersect_box.argtypes = [C.c_void_p, _f, _f, _f, _f, C.c_uint32, _f]
+        L.rtx_trace_shade.argtypes = [C.c_void_p, C.POINTER(Options), _f, _f, C.c_uint32, C.c_int32, C.c_int32, _f]
+        L.rtx_camera_points.argtypes = [C.c_void_p, C.POINTER(Camera), _f, C.c_uint32, _f, _f]
+        L.rtx_scene_set_flags.argtypes = [C.c_void_p, C.c_uint32]
         L.rtx_tiles_count.argtypes = [Rect, C.c_int32, C.c_int32, C.c_int32]
         L.rtx_render_tiles_dev.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Options), Rect, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -171,6 +179,43 @@ class Scene:
         out = np.zeros((max(1, i.ntris), 16), np.float32)
         _check(lib().rtx_scene_get_tris(self.h, fp(out)))
         return out[:i.ntris]
+
+    def build_reference_leafboxes(self, max_faces=0, iter_cap=0):
+        return _check(lib().rtx_scene_build_reference_leafboxes(self.h, max_faces, iter_cap))
+
+    def leafboxes(self):
+        nl, nf = C.c_uint32(), C.c_uint32()
+        _check(lib().rtx_scene_get_leafboxes(self.h, None, None, None, None, None, C.byref(nl), C.byref(nf)))
+        lo = np.zeros((nl.value, 3), np.float32)
+        hi = np.zeros((nl.value, 3), np.float32)
+        st = np.zeros(nl.value, np.uint32)
+        ct = np.zeros(nl.value, np.uint32)
+        fa = np.zeros(max(1, nf.value), np.int32)
+        _check(lib().rtx_scene_get_leafboxes(self.h, fp(lo), fp(hi), st.ctypes.data_as(_u), ct.ctypes.data_as(_u),
+                                             fa.ctypes.data_as(_i), None, None))
+        return [(lo[i], hi[i], fa[st[i]:st[i] + ct[i]].copy()) for i in range(nl.value)]
+
+    def intersect_box(self, bmin, bmax, o, d):
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        t = np.zeros(len(o), np.float32)
+        _check(lib().rtx_intersect_box(self.h, fp(np.ascontiguousarray(bmin, np.float32)),
+                                       fp(np.ascontiguousarray(bmax, np.float32)), fp(o), fp(d), len(o), fp(t)))
+        return t
+
+    def trace_shade(self, opts, o, d, bounce=0, inside=False):
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        rgb = np.zeros((len(o), 3), np.float32)
+        _check(lib().rtx_trace_shade(self.h, C.byref(opts), fp(o), fp(d), len(o), bounce, 1 if inside else 0, fp(rgb)))
+        return rgb
+
+    def camera_points(self, cam, ij):
+        ij = np.ascontiguousarray(ij, np.float32).reshape(-1, 2)
+        w = np.zeros((len(ij), 3), np.float32)
+        c = np.zeros(3, np.float32)
+        _check(lib().rtx_camera_points(self.h, C.byref(cam), fp(ij), len(ij), fp(w), fp(c)))
+        return w, c
 
     def commit(self, device=0):
         _check(lib().rtx_scene_commit(self.h, device))

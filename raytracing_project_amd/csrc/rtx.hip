@@ -71,6 +71,11 @@ struct rtx_scene {
   std::vector<float> spheres;
   std::vector<int32_t> sph_mat;
   std::vector<float> lights, slights;
+  std::vector<float> leaf_lo, leaf_hi;        // reference leaf list (divideBox_KD), 3 floats per leaf
+  std::vector<uint32_t> leaf_start, leaf_count;
+  std::vector<int32_t> leaf_faces;
+  bool have_leaves = false;
+  uint32_t flags = 0;
   // host-built acceleration data (rtx_scene_build)
   bool built = false;
   std::vector<float4> h_tri_leaf, h_face_nm;
@@ -84,8 +89,9 @@ struct rtx_scene {
   BvhBuildResult bvh;
   DevScene dev{};
   DevBuf d_nodes, d_tris, d_tri_face, d_face_nm, d_spheres, d_sph_mat, d_mats, d_lights;
+  DevBuf d_slights, d_leafboxes, d_leaf_faces, d_face_pos;
   // workspace
-  DevBuf w_rays[2], w_hits[2], w_parents, w_shadow_rays, w_shadow_hits, w_counters, w_io[6];
+  DevBuf w_rays[2], w_hits[2], w_parents, w_shadow_rays, w_shadow_hits, w_gi_rays, w_gi_hits, w_counters, w_io[6];
   EventPool events;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_spans, all_spans;
   size_t camera_span = (size_t)-1;   // index into trace_spans of the k_trace_camera launch
@@ -121,7 +127,8 @@ extern "C" int rtx_scene_create(const float* verts, uint32_t nverts, const uint3
 static void release_device(rtx_scene* s) {
   if (s->device >= 0) (void)hipSetDevice(s->device);
   DevBuf* bufs[] = {&s->d_nodes, &s->d_tris, &s->d_tri_face, &s->d_face_nm, &s->d_spheres, &s->d_sph_mat, &s->d_mats,
-                    &s->d_lights, &s->w_rays[0], &s->w_rays[1], &s->w_hits[0], &s->w_hits[1], &s->w_parents,
+                    &s->d_lights, &s->d_slights, &s->d_leafboxes, &s->d_leaf_faces, &s->d_face_pos, &s->w_gi_rays,
+                    &s->w_gi_hits, &s->w_rays[0], &s->w_rays[1], &s->w_hits[0], &s->w_hits[1], &s->w_parents,
                     &s->w_shadow_rays, &s->w_shadow_hits, &s->w_counters, &s->w_io[0], &s->w_io[1], &s->w_io[2],
                     &s->w_io[3], &s->w_io[4], &s->w_io[5]};
   for (DevBuf* b : bufs) b->release();
@@ -152,6 +159,14 @@ extern "C" int rtx_scene_set_spheres(rtx_scene* s, const float* cr4, const int32
   return RTX_OK;
 }
 
+extern "C" int rtx_scene_set_flags(rtx_scene* s, uint32_t flags) {
+  if (!s) return fail(RTX_EINVAL, "null scene");
+  if (flags & ~(uint32_t)RTX_FLAG_NO_ROOT_GATE) return fail(RTX_EINVAL, "unknown flag bits 0x%x", flags);
+  s->flags = flags;
+  s->committed = false;
+  return RTX_OK;
+}
+
 extern "C" int rtx_scene_set_lights(rtx_scene* s, const float* xyz, uint32_t n, const float* sxyzr, uint32_t m) {
   if (!s || (n && !xyz) || (m && !sxyzr)) return fail(RTX_EINVAL, "null argument");
   s->lights.assign(xyz, xyz + (size_t)n * 3);
@@ -165,6 +180,108 @@ static int upload(DevBuf& b, const std::vector<T>& v, hipStream_t st) {
   size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
   if (int rc = b.ensure(bytes)) return rc;
   if (!v.empty()) HIP_TRY(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+  return RTX_OK;
+}
+
+
+// ------------------------------------------------------------------ reference leaf list
+extern "C" int rtx_scene_set_leafboxes(rtx_scene* s, const float* bmin_xyz, const float* bmax_xyz, const uint32_t* start,
+                                       const uint32_t* count, uint32_t nleaves, const int32_t* faces, uint32_t nfaces) {
+  if (!s || (nleaves && (!bmin_xyz || !bmax_xyz || !start || !count)) || (nfaces && !faces)) return fail(RTX_EINVAL, "null argument");
+  const uint32_t ntris = (uint32_t)s->tri_mat.size();
+  for (uint32_t i = 0; i < nleaves; ++i)
+    if ((uint64_t)start[i] + count[i] > nfaces) return fail(RTX_EINVAL, "leaf %u exceeds the face list", i);
+  for (uint32_t i = 0; i < nfaces; ++i)
+    if (faces[i] < 0 || (uint32_t)faces[i] >= ntris) return fail(RTX_EINVAL, "leaf face id %d out of range", faces[i]);
+  s->leaf_lo.assign(bmin_xyz, bmin_xyz + (size_t)nleaves * 3);
+  s->leaf_hi.assign(bmax_xyz, bmax_xyz + (size_t)nleaves * 3);
+  s->leaf_start.assign(start, start + nleaves);
+  s->leaf_count.assign(count, count + nleaves);
+  s->leaf_faces.assign(faces, faces + nfaces);
+  s->have_leaves = true;
+  s->committed = false;
+  return RTX_OK;
+}
+
+// Flyscene::divideBox_KD with its helpers averagePoint, axisToDivide, isInBox
+// (src/flyscene.cpp:974-993,1070-1185) and Box(mesh) (src/box.h:41-85): the flat, lossy leaf
+// list that trace_global_illum and the debug ray walk.  One-off host work.
+// Returns the number of leaves, or RTX_ELIMIT when the reference's split would never
+// terminate (detected by an iteration cap).
+extern "C" int rtx_scene_build_reference_leafboxes(rtx_scene* s, int32_t max_faces, int64_t iter_cap) {
+  if (!s) return fail(RTX_EINVAL, "null scene");
+  const uint32_t ntris = (uint32_t)s->tri_mat.size();
+  const uint32_t nverts = (uint32_t)(s->verts.size() / 3);
+  if (max_faces <= 0) max_faces = (int32_t)std::sqrt((double)(ntris + 100));     // src/flyscene.cpp:79
+  if (iter_cap <= 0) iter_cap = 64ll * ntris + 4096;
+  struct QBox { float lo[3], hi[3]; std::vector<int32_t> faces; };
+  float mx[3] = {1.17549435e-38f, 1.17549435e-38f, 1.17549435e-38f};
+  float mn[3] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f};
+  for (uint32_t i = 0; i < nverts; ++i)
+    for (int k = 0; k < 3; ++k) {
+      float x = s->verts[3 * (size_t)i + k];
+      if (x > mx[k]) mx[k] = x;
+      if (x < mn[k]) mn[k] = x;
+    }
+  auto vtx = [&](int32_t f, int c, int k) { return s->verts[3 * (size_t)s->idx[3 * (size_t)f + c] + k]; };
+  auto in_box = [&](const float* lo, const float* hi, int32_t f) {
+    for (int c = 0; c < 3; ++c) {
+      const float x = vtx(f, c, 0), y = vtx(f, c, 1), z = vtx(f, c, 2);
+      if (hi[0] >= x && lo[0] <= x && hi[1] >= y && lo[1] <= y && hi[2] >= z && lo[2] <= z) return true;
+    }
+    return false;
+  };
+  std::vector<float> llo, lhi; std::vector<uint32_t> lstart, lcount; std::vector<int32_t> lfaces;
+  std::vector<QBox> queue(1);
+  std::memcpy(queue[0].lo, mn, 12); std::memcpy(queue[0].hi, mx, 12);
+  queue[0].faces.resize(ntris);
+  for (uint32_t i = 0; i < ntris; ++i) queue[0].faces[i] = (int32_t)i;
+  size_t head = 0;
+  int64_t iters = 0;
+  while (head < queue.size()) {
+    if (++iters > iter_cap) return fail(RTX_ELIMIT, "the reference's divideBox_KD does not terminate on this mesh (SURVEY F13)");
+    QBox box = std::move(queue[head]); ++head;
+    if (box.faces.size() <= (size_t)max_faces && !box.faces.empty()) {
+      for (int k = 0; k < 3; ++k) { llo.push_back(box.lo[k]); lhi.push_back(box.hi[k]); }
+      lstart.push_back((uint32_t)lfaces.size()); lcount.push_back((uint32_t)box.faces.size());
+      lfaces.insert(lfaces.end(), box.faces.begin(), box.faces.end());
+      continue;
+    }
+    int axis = -1; float best = 1.17549435e-38f;                       // axisToDivide: '<=' keeps the last of equals
+    for (int k = 0; k < 3; ++k) { float d = box.hi[k] - box.lo[k]; if (best <= d) { best = d; axis = k; } }
+    float sx = 0, sy = 0, sz = 0;                                       // averagePoint: running fp32 sums
+    for (int32_t f : box.faces) for (int c = 0; c < 3; ++c) { sx += vtx(f, c, 0); sy += vtx(f, c, 1); sz += vtx(f, c, 2); }
+    const float size = (float)(box.faces.size() * 3);
+    const float avg[3] = {sx / size, sy / size, sz / size};
+    const int ax = (axis == 0 || axis == 1) ? axis : 2;
+    QBox b1, b2;
+    std::memcpy(b1.lo, box.lo, 12); std::memcpy(b1.hi, box.hi, 12); b1.hi[ax] = avg[ax];
+    std::memcpy(b2.lo, box.lo, 12); std::memcpy(b2.hi, box.hi, 12); b2.lo[ax] = avg[ax];
+    for (int32_t f : box.faces) {
+      if (in_box(b1.lo, b1.hi, f)) b1.faces.push_back(f);
+      if (in_box(b2.lo, b2.hi, f)) b2.faces.push_back(f);
+    }
+    queue.push_back(std::move(b1));
+    queue.push_back(std::move(b2));
+    if (head > 4096 && head * 2 > queue.size()) { queue.erase(queue.begin(), queue.begin() + (long)head); head = 0; }
+  }
+  s->leaf_lo = llo; s->leaf_hi = lhi; s->leaf_start = lstart; s->leaf_count = lcount; s->leaf_faces = lfaces;
+  s->have_leaves = true;
+  s->committed = false;
+  return (int)lstart.size();
+}
+
+extern "C" int rtx_scene_get_leafboxes(const rtx_scene* s, float* bmin_xyz, float* bmax_xyz, uint32_t* start, uint32_t* count,
+                                       int32_t* faces, uint32_t* nleaves, uint32_t* nfaces) {
+  if (!s) return fail(RTX_EINVAL, "null scene");
+  if (!s->have_leaves) return fail(RTX_ESTATE, "no leaf list (rtx_scene_build_reference_leafboxes / rtx_scene_set_leafboxes)");
+  if (nleaves) *nleaves = (uint32_t)s->leaf_start.size();
+  if (nfaces) *nfaces = (uint32_t)s->leaf_faces.size();
+  if (bmin_xyz) std::memcpy(bmin_xyz, s->leaf_lo.data(), s->leaf_lo.size() * 4);
+  if (bmax_xyz) std::memcpy(bmax_xyz, s->leaf_hi.data(), s->leaf_hi.size() * 4);
+  if (start) std::memcpy(start, s->leaf_start.data(), s->leaf_start.size() * 4);
+  if (count) std::memcpy(count, s->leaf_count.data(), s->leaf_count.size() * 4);
+  if (faces) std::memcpy(faces, s->leaf_faces.data(), s->leaf_faces.size() * 4);
   return RTX_OK;
 }
 
@@ -305,12 +422,32 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   if (int rc = upload(s->d_sph_mat, dsm, s->stream)) return rc;
   if (int rc = upload(s->d_mats, dm, s->stream)) return rc;
   if (int rc = upload(s->d_lights, dl, s->stream)) return rc;
+  std::vector<float4> dsl(std::max<size_t>(s->slights.size() / 4, 1));
+  for (size_t i = 0; i < s->slights.size() / 4; ++i) dsl[i] = make_float4(s->slights[4 * i], s->slights[4 * i + 1], s->slights[4 * i + 2], s->slights[4 * i + 3]);
+  const size_t nleaf = s->have_leaves ? s->leaf_start.size() : 0;
+  std::vector<float4> dlb(std::max<size_t>(nleaf * 2, 1));
+  for (size_t i = 0; i < nleaf; ++i) {
+    float sw, cw; std::memcpy(&sw, &s->leaf_start[i], 4); std::memcpy(&cw, &s->leaf_count[i], 4);
+    dlb[2 * i] = make_float4(s->leaf_lo[3 * i], s->leaf_lo[3 * i + 1], s->leaf_lo[3 * i + 2], sw);
+    dlb[2 * i + 1] = make_float4(s->leaf_hi[3 * i], s->leaf_hi[3 * i + 1], s->leaf_hi[3 * i + 2], cw);
+  }
+  std::vector<int32_t> dlf = s->leaf_faces; if (dlf.empty()) dlf.push_back(0);
+  std::vector<int32_t> fpos(std::max<uint32_t>(ntris, 1), 0);
+  for (uint32_t k = 0; k < ntris; ++k) fpos[(size_t)tri_face[k]] = (int32_t)k;
+  if (int rc = upload(s->d_slights, dsl, s->stream)) return rc;
+  if (int rc = upload(s->d_leafboxes, dlb, s->stream)) return rc;
+  if (int rc = upload(s->d_leaf_faces, dlf, s->stream)) return rc;
+  if (int rc = upload(s->d_face_pos, fpos, s->stream)) return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
 
   DevScene& d = s->dev;
   d.nodes = s->d_nodes.as<float4>(); d.tris = s->d_tris.as<float4>(); d.tri_face = s->d_tri_face.as<int>();
   d.face_nm = s->d_face_nm.as<float4>(); d.spheres = s->d_spheres.as<float4>(); d.sph_mat = s->d_sph_mat.as<int>();
   d.mats = s->d_mats.as<DevMat>(); d.lights = s->d_lights.as<float4>();
+  d.slights = s->d_slights.as<float4>(); d.leafboxes = s->d_leafboxes.as<float4>();
+  d.leaf_faces = s->d_leaf_faces.as<int>(); d.face_pos = s->d_face_pos.as<int>();
+  d.nsl = (uint32_t)(s->slights.size() / 4); d.nleafboxes = (uint32_t)nleaf;
+  d.flags = s->flags; d.pad1 = 0;
   d.ntris = ntris; d.nwild = s->nwild; d.nspheres = (uint32_t)(s->spheres.size() / 4); d.nlights = (uint32_t)(s->lights.size() / 3);
   d.nmats = (uint32_t)s->mats.size();
   for (int k = 0; k < 3; ++k) { d.root_lo[k] = s->root_lo[k]; d.root_hi[k] = s->root_hi[k]; }
@@ -319,7 +456,8 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   rtx_scene_info& in = s->info;
   in.nspheres = d.nspheres; in.nlights = d.nlights; in.nmaterials = d.nmats;
   in.device_bytes = s->d_nodes.cap + s->d_tris.cap + s->d_tri_face.cap + s->d_face_nm.cap + s->d_spheres.cap +
-                    s->d_sph_mat.cap + s->d_mats.cap + s->d_lights.cap;
+                    s->d_sph_mat.cap + s->d_mats.cap + s->d_lights.cap + s->d_slights.cap + s->d_leafboxes.cap +
+                    s->d_leaf_faces.cap + s->d_face_pos.cap;
   s->committed = true;
   return RTX_OK;
 }
@@ -508,13 +646,16 @@ static int make_camera(const rtx_camera* cam, rtx_rect r, DevCamera* C) {
 
 static int render_impl(rtx_scene* s, const DevCamera& C, uint32_t npix, uint32_t nblocks, const rtx_options* opt,
                        float* rgb, float* t, int32_t* face);
+static int check_render_args(rtx_scene* s, const rtx_camera* cam, const rtx_options* opt, const float* rgb);
 
 static int check_render_args(rtx_scene* s, const rtx_camera* cam, const rtx_options* opt, const float* rgb) {
   if (!cam || !opt) return fail(RTX_EINVAL, "null camera/options");
-  if (opt->refraction || opt->gi_rays) return fail(RTX_EINVAL, "refraction / gi_rays are not implemented on the GPU path yet");
   if (opt->max_bounces < 0 || opt->max_bounces > 16) return fail(RTX_ELIMIT, "max_bounces must be in [0,16]");
-  if (!s->slights.empty() && rgb) return fail(RTX_EINVAL, "spherical lights are not implemented on the GPU path yet");
-  if (rgb && s->dev.nlights == 0) return fail(RTX_EINVAL, "shading needs at least one light (the reference divides by the light count)");
+  if (opt->gi_rays < 0 || opt->gi_rays > 64) return fail(RTX_ELIMIT, "gi_rays must be in [0,64]");
+  if (opt->refraction && opt->reflection && opt->max_bounces > 8) return fail(RTX_ELIMIT, "reflection + refraction trees are limited to 8 bounces");
+  if (rgb && opt->gi_rays > 0 && !s->have_leaves)
+    return fail(RTX_ESTATE, "gi_rays needs the reference leaf list (rtx_scene_build_reference_leafboxes) before commit");
+  if (rgb && s->dev.nlights + s->dev.nsl == 0) return fail(RTX_EINVAL, "shading needs at least one light (the reference divides by the light count)");
   return RTX_OK;
 }
 
@@ -555,67 +696,94 @@ extern "C" int rtx_render_tiles_dev(rtx_scene* s, const rtx_camera* cam, const r
   return render_impl(s, C, npix, nblocks, opt, rgb, t, face);
 }
 
-static int render_impl(rtx_scene* s, const DevCamera& C, uint32_t npix, uint32_t tiles, const rtx_options* opt,
-                       float* rgb, float* t, int32_t* face) {
-  const uint32_t NL = s->dev.nlights;
+// The generation loop of the ray queue.  Primary nodes are either the pixels of a camera
+// rectangle (implicit rays) or `n0` caller rays already converted to queue records in
+// w_rays[0] (Flyscene::traceRay(bounce0, ray, inside)).
+struct Primary { bool camera; DevCamera C; uint32_t n0, tiles; int bounce0; };
+
+static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt, float* rgb, float* t, int32_t* face) {
+  const uint32_t NLS = s->dev.nlights + 5u * s->dev.nsl;
+  const uint32_t G = (uint32_t)std::max(opt->gi_rays, 0);
   const bool shade = rgb != nullptr;
-  if (int rc = s->w_hits[0].ensure((size_t)npix * 8)) return rc;
-  if (int rc = s->w_counters.ensure(4 * 64)) return rc;
+  const bool tree = opt->reflection && opt->refraction;
+  const bool any_child = opt->reflection || opt->refraction;
+  const int max_gen = (shade && any_child) ? std::max(0, opt->max_bounces - pr.bounce0) : 0;
+  const uint64_t max_nodes = tree ? ((uint64_t)pr.n0 << max_gen) : pr.n0;
+  if (max_nodes * std::max<uint64_t>(std::max(NLS, G), 1) >= (1ull << 32)) return fail(RTX_ELIMIT, "ray queue would exceed 2^32 entries");
+  if (int rc = s->w_hits[0].ensure((size_t)pr.n0 * 8)) return rc;
   if (shade) {
-    if (int rc = s->w_parents.ensure((size_t)npix * 4)) return rc;
+    if (int rc = s->w_parents.ensure((size_t)max_nodes * 4)) return rc;
     if (opt->shadows) {
-      if (int rc = s->w_shadow_rays.ensure((size_t)npix * NL * 32)) return rc;
-      if (int rc = s->w_shadow_hits.ensure((size_t)npix * NL * 8)) return rc;
+      if (int rc = s->w_shadow_rays.ensure((size_t)max_nodes * NLS * 32)) return rc;
+      if (int rc = s->w_shadow_hits.ensure((size_t)max_nodes * NLS * 8)) return rc;
     }
-    if (opt->reflection && opt->max_bounces > 0) {
-      if (int rc = s->w_rays[0].ensure((size_t)npix * 32)) return rc;
-      if (int rc = s->w_rays[1].ensure((size_t)npix * 32)) return rc;
-      if (int rc = s->w_hits[1].ensure((size_t)npix * 8)) return rc;
+    if (G) {
+      if (int rc = s->w_gi_rays.ensure((size_t)max_nodes * G * 32)) return rc;
+      if (int rc = s->w_gi_hits.ensure((size_t)max_nodes * G * 8)) return rc;
+    }
+    if (max_gen > 0) {
+      if (int rc = s->w_rays[0].ensure((size_t)max_nodes * 32)) return rc;
+      if (int rc = s->w_rays[1].ensure((size_t)max_nodes * 32)) return rc;
+      if (int rc = s->w_hits[1].ensure((size_t)max_nodes * 8)) return rc;
     }
   }
-  stats_begin(s);
-  // counters: per generation g, slots [4g] = #parents, [4g+1] = #rays of generation g+1
-  const int max_gen = shade && opt->reflection ? opt->max_bounces : 0;
-  if (int rc = s->w_counters.ensure((size_t)(max_gen + 2) * 16)) return rc;
+  // counters: per generation g, [4g] = #parents, [4g+1] = #nodes of generation g+1, [4g+2] = #refraction rays spawned
+  if (int rc = s->w_counters.ensure((size_t)(max_gen + 2) * 16 + 16)) return rc;
   HIP_TRY(hipMemsetAsync(s->w_counters.p, 0, (size_t)(max_gen + 2) * 16, s->stream));
   uint32_t* cnt = s->w_counters.as<uint32_t>();
+  uint32_t* n0_dev = cnt + (size_t)(max_gen + 2) * 4;       // device copy of n0 for the queue kernels
+  HIP_TRY(hipMemcpyAsync(n0_dev, &pr.n0, 4, hipMemcpyHostToDevice, s->stream));
 
   span_begin(s, true);
-  s->camera_span = s->trace_spans.size() - 1;
-  hipLaunchKernelGGL(k_trace_camera, dim3(std::min<uint32_t>(tiles, (uint32_t)s->ncu * 64)), dim3(kBlock), 0, s->stream, s->dev, C,
-                     tiles, s->w_hits[0].as<uint2>());
+  if (pr.camera) {
+    s->camera_span = s->trace_spans.size() - 1;
+    hipLaunchKernelGGL(k_trace_camera, dim3(std::min<uint32_t>(pr.tiles, (uint32_t)s->ncu * 64)), dim3(kBlock), 0, s->stream,
+                       s->dev, pr.C, pr.tiles, s->w_hits[0].as<uint2>());
+  } else {
+    hipLaunchKernelGGL(k_trace_queue, dim3(grid_for(s, pr.n0)), dim3(kBlock), 0, s->stream, s->dev, s->w_rays[0].as<float4>(),
+                       n0_dev, 1u, s->w_hits[0].as<uint2>());
+  }
   span_end(s, true);
 
+  const float th_gi = G ? (float)(M_PI * 2 / (double)G) : 0.0f;      // Ray::resendRay: float theta = M_PI * 2 / n
+  const float th_sl = (float)(M_PI * 2 / 4);                          // Shader::getNPointsOnCircle with n = 4
+  uint64_t bound = pr.n0;                                             // host-side upper bound of the node count
   for (int g = 0; g <= max_gen; ++g) {
     const int cur = g & 1, nxt = cur ^ 1;
-    ShadeArgs A;
-    A.S = s->dev; A.C = C; A.gen = g; A.max_bounces = opt->max_bounces; A.reflection = opt->reflection;
-    A.shadows = opt->shadows; A.skip_zero_weight = opt->skip_zero_weight; A.npix = npix;
-    // generation g > 0 rays live in w_rays[cur]; their count is counters[4(g-1)+1]
-    A.rays = g == 0 ? nullptr : s->w_rays[cur].as<float4>();
+    PipeArgs A;
+    A.S = s->dev; A.C = pr.C; A.bounce = pr.bounce0 + g; A.from_camera = (pr.camera && g == 0) ? 1 : 0; A.first_gen = g == 0;
+    A.max_bounces = opt->max_bounces; A.reflection = opt->reflection; A.refraction = opt->refraction; A.gi_rays = (int)G;
+    A.shadows = opt->shadows; A.skip_zero_weight = opt->skip_zero_weight; A.atomic_accum = tree ? 1 : 0;
+    A.n0 = pr.n0;
     A.nrays = g == 0 ? nullptr : cnt + 4 * (g - 1) + 1;
+    A.rays = (pr.camera && g == 0) ? nullptr : s->w_rays[cur].as<float4>();
     A.hits = (g == 0 ? s->w_hits[0] : s->w_hits[1]).as<uint2>();
     A.rgb = rgb; A.out_t = t; A.out_face = face;
     A.parents = s->w_parents.as<uint32_t>();
-    A.shadow_rays = s->w_shadow_rays.as<float4>();
+    A.shadow_rays = s->w_shadow_rays.as<float4>(); A.shadow_hits = s->w_shadow_hits.as<uint2>();
+    A.gi_q = s->w_gi_rays.as<float4>(); A.gi_hits = s->w_gi_hits.as<uint2>();
     A.next_rays = s->w_rays[nxt].as<float4>();
     A.counters = cnt + 4 * g;
-    hipLaunchKernelGGL(k_shade, dim3(grid_for(s, npix)), dim3(kBlock), 0, s->stream, A);
+    A.gi_sin = sinf(th_gi); A.gi_cos = cosf(th_gi); A.sl_sin = sinf(th_sl); A.sl_cos = cosf(th_sl);
+    hipLaunchKernelGGL(k_shade, dim3(grid_for(s, bound)), dim3(kBlock), 0, s->stream, A);
     if (!shade) break;
-    if (opt->shadows) {
+    if (opt->shadows && NLS) {
       span_begin(s, true);
-      hipLaunchKernelGGL(k_trace_queue, dim3(grid_for(s, (size_t)npix * NL)), dim3(kBlock), 0, s->stream, s->dev,
-                         s->w_shadow_rays.as<float4>(), cnt + 4 * g, NL, s->w_shadow_hits.as<uint2>());
+      hipLaunchKernelGGL(k_trace_queue, dim3(grid_for(s, bound * NLS)), dim3(kBlock), 0, s->stream, s->dev,
+                         s->w_shadow_rays.as<float4>(), cnt + 4 * g, NLS, s->w_shadow_hits.as<uint2>());
       span_end(s, true);
     }
-    ResolveArgs R;
-    R.S = s->dev; R.C = C; R.gen = g; R.shadows = opt->shadows; R.npix = npix;
-    R.rays = A.rays; R.hits = A.hits; R.parents = A.parents; R.nparents = cnt + 4 * g;
-    R.shadow_rays = A.shadow_rays; R.shadow_hits = s->w_shadow_hits.as<uint2>(); R.rgb = rgb;
-    hipLaunchKernelGGL(k_resolve, dim3(grid_for(s, npix)), dim3(kBlock), 0, s->stream, R);
-    if (g < max_gen) {
+    if (G) {
       span_begin(s, true);
-      hipLaunchKernelGGL(k_trace_queue, dim3(grid_for(s, npix)), dim3(kBlock), 0, s->stream, s->dev, s->w_rays[nxt].as<float4>(),
+      hipLaunchKernelGGL(k_trace_gi, dim3(grid_for(s, bound * G)), dim3(kBlock), 0, s->stream, s->dev, s->w_gi_rays.as<float4>(),
+                         cnt + 4 * g, G, s->w_gi_hits.as<uint2>());
+      span_end(s, true);
+    }
+    hipLaunchKernelGGL(k_resolve, dim3(grid_for(s, bound)), dim3(kBlock), 0, s->stream, A);
+    if (g < max_gen) {
+      if (tree) bound *= 2;
+      span_begin(s, true);
+      hipLaunchKernelGGL(k_trace_queue, dim3(grid_for(s, bound)), dim3(kBlock), 0, s->stream, s->dev, s->w_rays[nxt].as<float4>(),
                          cnt + 4 * g + 1, 1u, s->w_hits[1].as<uint2>());
       span_end(s, true);
     }
@@ -623,6 +791,21 @@ static int render_impl(rtx_scene* s, const DevCamera& C, uint32_t npix, uint32_t
   std::vector<uint32_t> hc((size_t)(max_gen + 2) * 4);
   HIP_TRY(hipMemcpyAsync(hc.data(), s->w_counters.p, hc.size() * 4, hipMemcpyDeviceToHost, s->stream));
   if (int rc = stats_end(s)) return rc;
+  if (shade) {
+    for (int g = 0; g <= max_gen; ++g) {
+      if (opt->shadows) s->stats.rays_shadow += (uint64_t)hc[4 * g] * NLS;
+      s->stats.rays_gi += (uint64_t)hc[4 * g] * G;
+      if (g < max_gen) { s->stats.rays_refraction += hc[4 * g + 2]; s->stats.rays_reflection += hc[4 * g + 1] - hc[4 * g + 2]; }
+    }
+  }
+  return RTX_OK;
+}
+
+static int render_impl(rtx_scene* s, const DevCamera& C, uint32_t npix, uint32_t tiles, const rtx_options* opt,
+                       float* rgb, float* t, int32_t* face) {
+  stats_begin(s);
+  Primary pr; pr.camera = true; pr.C = C; pr.n0 = npix; pr.tiles = tiles; pr.bounce0 = 0;
+  if (int rc = run_pipeline(s, pr, opt, rgb, t, face)) return rc;
   uint64_t live = npix;
   if (C.ts) {   // partial edge tiles: count only slots that are pixels of the rectangle
     live = 0;
@@ -635,12 +818,76 @@ static int render_impl(rtx_scene* s, const DevCamera& C, uint32_t npix, uint32_t
     }
   }
   s->stats.rays_primary = live;
-  if (shade) {
-    for (int g = 0; g <= max_gen; ++g) {
-      if (opt->shadows) s->stats.rays_shadow += (uint64_t)hc[4 * g] * NL;
-      if (g < max_gen) s->stats.rays_reflection += hc[4 * g + 1];
-    }
-  }
+  return RTX_OK;
+}
+
+// Flyscene::traceRay(bounce, Ray(o, d), insideObject) for n caller rays (src/flyscene.cpp:587-601).
+extern "C" int rtx_trace_shade(rtx_scene* s, const rtx_options* opt, const float* o, const float* d, uint32_t n, int32_t bounce,
+                               int32_t inside, float* rgb) {
+  if (int rc = check_ready(s)) return rc;
+  if (n == 0) return RTX_OK;
+  if (!opt || !o || !d || !rgb) return fail(RTX_EINVAL, "null argument");
+  if (n >= (1u << 31)) return fail(RTX_ELIMIT, "too many rays");
+  if (bounce < 0) return fail(RTX_EINVAL, "bounce must be >= 0");
+  rtx_camera dummy{};
+  if (int rc = check_render_args(s, &dummy, opt, rgb)) return rc;
+  const size_t b3 = (size_t)n * 12;
+  if (int rc = s->w_io[0].ensure(b3)) return rc;
+  if (int rc = s->w_io[1].ensure(b3)) return rc;
+  if (int rc = s->w_io[2].ensure(b3)) return rc;
+  const bool tree = opt->reflection && opt->refraction;
+  const int max_gen = std::max(0, opt->max_bounces - bounce);
+  const uint64_t max_nodes = tree ? ((uint64_t)n << max_gen) : n;
+  if (int rc = s->w_rays[0].ensure((size_t)max_nodes * 32)) return rc;
+  HIP_TRY(hipMemcpyAsync(s->w_io[0].p, o, b3, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->w_io[1].p, d, b3, hipMemcpyHostToDevice, s->stream));
+  stats_begin(s);
+  hipLaunchKernelGGL(k_make_nodes, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->w_io[0].as<float>(), s->w_io[1].as<float>(), n,
+                     inside ? 1 : 0, s->w_rays[0].as<float4>());
+  Primary pr; pr.camera = false; std::memset(&pr.C, 0, sizeof pr.C); pr.n0 = n; pr.tiles = 0; pr.bounce0 = bounce;
+  if (int rc = run_pipeline(s, pr, opt, s->w_io[2].as<float>(), nullptr, nullptr)) return rc;
+  s->stats.rays_primary = n;
+  HIP_TRY(hipMemcpy(rgb, s->w_io[2].p, b3, hipMemcpyDeviceToHost));
+  return RTX_OK;
+}
+
+// Camera::screenToWorld / getCenter for n raster positions (tucano/camera.hpp:115-118,155-173).
+extern "C" int rtx_camera_points(rtx_scene* s, const rtx_camera* cam, const float* ij, uint32_t n, float* world, float* center) {
+  if (int rc = check_ready(s)) return rc;
+  if (!cam || (n && (!ij || !world))) return fail(RTX_EINVAL, "null argument");
+  DevCamera C;
+  rtx_rect r{0, 0, 1, 1};
+  if (int rc = make_camera(cam, r, &C)) return rc;
+  if (center) { center[0] = C.origin[0]; center[1] = C.origin[1]; center[2] = C.origin[2]; }
+  if (n == 0) return RTX_OK;
+  if (int rc = s->w_io[0].ensure((size_t)n * 8)) return rc;
+  if (int rc = s->w_io[1].ensure((size_t)n * 12)) return rc;
+  HIP_TRY(hipMemcpyAsync(s->w_io[0].p, ij, (size_t)n * 8, hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(k_camera_points, dim3((n + 255) / 256), dim3(256), 0, s->stream, C, s->w_io[0].as<float>(), n, s->w_io[1].as<float>());
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(world, s->w_io[1].p, (size_t)n * 12, hipMemcpyDeviceToHost));
+  return RTX_OK;
+}
+
+// Flyscene::intersectBox(box, origin, dest) (src/flyscene.cpp:906-972) for n rays against one box:
+// t of Intersect::BoxObject::intersects (may be negative; INFINITY = miss).
+extern "C" int rtx_intersect_box(rtx_scene* s, const float* bmin, const float* bmax, const float* o, const float* d, uint32_t n,
+                                 float* t) {
+  if (int rc = check_ready(s)) return rc;
+  if (n == 0) return RTX_OK;
+  if (!bmin || !bmax || !o || !d || !t) return fail(RTX_EINVAL, "null argument");
+  const size_t b3 = (size_t)n * 12;
+  if (int rc = s->w_io[0].ensure(b3)) return rc;
+  if (int rc = s->w_io[1].ensure(b3)) return rc;
+  if (int rc = s->w_io[2].ensure((size_t)n * 4)) return rc;
+  HIP_TRY(hipMemcpyAsync(s->w_io[0].p, o, b3, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->w_io[1].p, d, b3, hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(k_ref_box, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->w_io[0].as<float>(), s->w_io[1].as<float>(), n,
+                     bmin[0], bmin[1], bmin[2], bmax[0], bmax[1], bmax[2], s->w_io[2].as<float>());
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(t, s->w_io[2].p, (size_t)n * 4, hipMemcpyDeviceToHost));
   return RTX_OK;
 }
 

@@ -30,7 +30,13 @@ struct DevScene {
   const int* sph_mat;
   const DevMat* mats;
   const float4* lights;    // point lights {xyz, 0}
+  const float4* slights;   // spherical lights {center, radius}
+  const float4* leafboxes; // reference leaf list (GI only): {bmin, start bits}, {bmax, count bits}
+  const int* leaf_faces;   // mesh face ids of the leaf lists
+  const int* face_pos;     // mesh face id -> position in tris
   uint32_t ntris, nspheres, nlights, nmats;
+  uint32_t nsl, nleafboxes;
+  uint32_t flags, pad1;           // bit 0: skip the reference's root-box gate (intersectTriangle semantics)
   float root_lo[3], root_hi[3];   // Box(mesh) of the reference, used as its root gate
   uint32_t root_entry;            // traversal entry of the BVH root
   uint32_t nwild;                 // ill-conditioned triangles [ntris - nwild, ntris): tested by every ray
@@ -147,7 +153,7 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& S, V3 o, V3 d1, uint3
   if (S.ntris == 0) return best;
   // intersectBox / intersectTriangle rebuild the Ray, re-normalising d1 (src/flyscene.cpp:845,965)
   const V3 d = normalized(d1);
-  if (!(ref_box_t(o, d, S.root_lo, S.root_hi) != INFINITY)) return best;
+  if (!(S.flags & 1u) && !(ref_box_t(o, d, S.root_lo, S.root_hi) != INFINITY)) return best;
 
   // slab constants for the padded BVH boxes (culling only; not part of the parity contract)
   // |1/d| is clamped so that an axis-parallel ray gives huge finite slab distances of the
@@ -289,6 +295,39 @@ __global__ void k_make_rays(const float* o, const float* d, uint32_t n, float4* 
   rays[2 * (size_t)i + 1] = make_float4(d1.x, d1.y, d1.z, 0.0f);
 }
 
+// Ray ctor over caller rays for Flyscene::traceRay: queue records with pixel = ray index.
+__global__ void k_make_nodes(const float* o, const float* d, uint32_t n, int inside, float4* rays) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const V3 d1 = normalized(v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
+  rays[2 * (size_t)i] = make_float4(o[3 * i], o[3 * i + 1], o[3 * i + 2], __uint_as_float(i | (inside ? 0x80000000u : 0u)));
+  rays[2 * (size_t)i + 1] = make_float4(d1.x, d1.y, d1.z, 1.0f);
+}
+// Flyscene::intersectBox: Ray ctor + Intersect::BoxObject::intersects for one box.
+__global__ void k_ref_box(const float* o, const float* d, uint32_t n, float lx, float ly, float lz, float hx, float hy, float hz,
+                          float* t) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const V3 d1 = normalized(v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
+  const float lo[3] = {lx, ly, lz}, hi[3] = {hx, hy, hz};
+  t[i] = ref_box_t(v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), d1, lo, hi);
+}
+
+// Camera::screenToWorld for caller pixel coordinates (tucano/camera.hpp:155-173): the world
+// point on the image plane (before the Ray ctor normalises the direction).
+__global__ void k_camera_points(DevCamera C, const float* ij, uint32_t n, float* world) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float nx = (float)(2.0 * (double)(ij[2 * i] - C.vp[0]) / (double)C.vp[2] - 1.0);
+  float ny = (float)(1.0 - 2.0 * (double)(ij[2 * i + 1] - C.vp[1]) / (double)C.vp[3]);
+  const float nz = -1.0f;
+  nx *= C.aspect_scale;
+  ny *= C.scale;
+  world[3 * i] = ((C.inv34[0] * nx + C.inv34[1] * ny) + C.inv34[2] * nz) + C.inv34[3] * 1.0f;
+  world[3 * i + 1] = ((C.inv34[4] * nx + C.inv34[5] * ny) + C.inv34[6] * nz) + C.inv34[7] * 1.0f;
+  world[3 * i + 2] = ((C.inv34[8] * nx + C.inv34[9] * ny) + C.inv34[10] * nz) + C.inv34[11] * 1.0f;
+}
+
 // Unpack hit records of caller rays into the HitInfo fields (src/hitInfo.h:4-16).
 __global__ void k_unpack_hits(DevScene S, const float4* rays, const uint2* hits, uint32_t n, float* t, int* face,
                               float* normal, float* point, int* mat) {
@@ -323,38 +362,49 @@ __global__ void k_unpack_hits(DevScene S, const float4* rays, const uint2* hits,
 }
 
 // ---------------------------------------------------------------- shading pipeline
-struct ShadeArgs {
+// One "node" = one traceRay call of the reference: a ray at bounce b for pixel p with the
+// product of blend weights on the way down (throughput) and the insideObject flag.
+// Generation g holds all nodes of bounce b0 + g; each generation is
+//   trace -> k_shade (spawn shadow / GI / child rays, compacted) -> trace queues -> k_resolve.
+struct PipeArgs {
   DevScene S;
   DevCamera C;
-  int gen;                  // bounce index of the rays being shaded
-  int max_bounces, reflection, shadows, skip_zero_weight;
-  uint32_t npix;            // rays of generation 0 (= pixels)
-  const float4* rays;       // generation > 0: queue records {o, pixel}, {d1, throughput}
-  const uint32_t* nrays;    // generation > 0: device-side count
+  int bounce;            // bounce index of the nodes of this generation
+  int from_camera;       // nodes are the pixels of C (implicit rays); else queue records
+  int first_gen;         // first generation of the call: initialises the output pixels
+  int max_bounces, reflection, refraction, gi_rays, shadows, skip_zero_weight;
+  int atomic_accum;      // several nodes of one generation may share a pixel (refraction tree)
+  uint32_t n0;           // node count when from_camera / first generation from a caller queue
+  const uint32_t* nrays; // device-side node count otherwise
+  const float4* rays;    // {o, pixel | inside<<31}, {d1, throughput}
   const uint2* hits;
-  float* rgb;               // row-major, 3 floats per pixel (may be null)
-  float* out_t; int* out_face;   // generation 0 only (may be null)
-  uint32_t* parents;        // compacted list of rays that hit something
-  float4* shadow_rays;      // parents x nlights records
-  float4* next_rays;        // reflection rays of generation gen+1
-  uint32_t* counters;       // [0] = #parents, [1] = #next rays
+  float* rgb; float* out_t; int* out_face;
+  uint32_t* parents;     // compacted list of nodes that hit something
+  float4* shadow_rays;   // parents x light samples
+  const uint2* shadow_hits;
+  float4* gi_q;          // parents x gi_rays
+  const uint2* gi_hits;  // {t bits (0 = nothing), material id}
+  float4* next_rays;     // nodes of the next generation
+  uint32_t* counters;    // [0] = #parents, [1] = #next nodes
+  float gi_sin, gi_cos;  // sinf/cosf of (float)(2*pi / gi_rays), evaluated on the host (glibc, like the reference)
+  float sl_sin, sl_cos;  // same for the 4-point ring of spherical lights
 };
 
-struct RayRec { V3 o, d1; uint32_t pixel; float thr; bool valid; };
+struct RayRec { V3 o, d1; uint32_t pixel; float thr; bool inside; bool valid; };
 
-__device__ __forceinline__ RayRec load_ray(int gen, const DevCamera& C, const float4* rays, uint32_t i) {
+__device__ __forceinline__ RayRec load_node(const PipeArgs& A, uint32_t i) {
   RayRec r;
-  if (gen == 0) {
+  if (A.from_camera) {
     int x, y;
-    r.valid = slot_pixel(C, i, &x, &y);
-    camera_ray(C, C.x0 + x, C.y0 + y, &r.o, &r.d1);
-    r.pixel = i; r.thr = 1.0f;
+    r.valid = slot_pixel(A.C, i, &x, &y);
+    camera_ray(A.C, A.C.x0 + x, A.C.y0 + y, &r.o, &r.d1);
+    r.pixel = i; r.thr = 1.0f; r.inside = false;
     return r;
-  } else {
-    const float4 ro = rays[2 * (size_t)i], rd = rays[2 * (size_t)i + 1];
-    r.o = v3(ro.x, ro.y, ro.z); r.d1 = v3(rd.x, rd.y, rd.z);
-    r.pixel = __float_as_uint(ro.w); r.thr = rd.w;
   }
+  const float4 ro = A.rays[2 * (size_t)i], rd = A.rays[2 * (size_t)i + 1];
+  r.o = v3(ro.x, ro.y, ro.z); r.d1 = v3(rd.x, rd.y, rd.z);
+  const uint32_t pw = __float_as_uint(ro.w);
+  r.pixel = pw & 0x7FFFFFFFu; r.inside = (pw >> 31) != 0; r.thr = rd.w;
   r.valid = true;
   return r;
 }
@@ -387,6 +437,50 @@ __device__ __forceinline__ DevMat material_of(const DevScene& S, int id) {
   return S.mats[id];
 }
 
+// Eigen::AngleAxisf(theta, axis).toRotationMatrix() (Eigen/src/Geometry/AngleAxis.h:218-243), row-major
+__device__ __forceinline__ void angle_axis_matrix(float s, float c, V3 axis, float* m) {
+  const V3 sin_axis = s * axis;
+  const V3 cos1_axis = (1.0f - c) * axis;
+  float tmp;
+  tmp = cos1_axis.x * axis.y; m[1] = tmp - sin_axis.z; m[3] = tmp + sin_axis.z;
+  tmp = cos1_axis.x * axis.z; m[2] = tmp + sin_axis.y; m[6] = tmp - sin_axis.y;
+  tmp = cos1_axis.y * axis.z; m[5] = tmp - sin_axis.x; m[7] = tmp + sin_axis.x;
+  m[0] = cos1_axis.x * axis.x + c; m[4] = cos1_axis.y * axis.y + c; m[8] = cos1_axis.z * axis.z + c;
+}
+// Position of light sample ls seen from hit point P: the point lights, then per spherical
+// light the 4 ring points of Shader::getNPointsOnCircle + its centre (src/flyscene.cpp:616-626,
+// src/ShaderLib.h:11-31).  *weight = 1 or 1/5 is applied by the caller as a division.
+__device__ __forceinline__ V3 light_sample(const PipeArgs& A, V3 P, uint32_t ls, bool* fifth) {
+  const DevScene& S = A.S;
+  if (ls < S.nlights) { const float4 L = S.lights[ls]; *fifth = false; return v3(L.x, L.y, L.z); }
+  *fifth = true;
+  const uint32_t j = (ls - S.nlights) / 5u, k = (ls - S.nlights) % 5u;
+  const float4 sl = S.slights[j];
+  const V3 center = v3(sl.x, sl.y, sl.z);
+  if (k == 4u) return center;
+  const V3 normal = normalized(P - center);
+  V3 not_normal = v3(1.0f, 0.0f, 0.0f);
+  const bool eq = (normal.x == 1.0f && normal.y == 0.0f && normal.z == 0.0f) || (-normal.x == 1.0f && -normal.y == 0.0f && -normal.z == 0.0f);
+  if (eq) not_normal = normalized(v3(1.0f, 1.0f, 0.0f));
+  V3 rv = normalized(cross(normal, not_normal)) * sl.w;
+  float m[9];
+  angle_axis_matrix(A.sl_sin, A.sl_cos, normal, m);
+  for (uint32_t i = 0; i < k; ++i) rv = mat3_mul(m, rv);
+  return rv + center;
+}
+__device__ __forceinline__ uint32_t light_samples(const DevScene& S) { return S.nlights + 5u * S.nsl; }
+
+// Ray::refractRay (src/Ray.h:36-42); pow(float,int) and sqrt run in double under libstdc++
+__device__ __forceinline__ V3 refract_dir(V3 n, V3 view, float n1, float n2) {
+  const float dt = dot(view, n);
+  const float numerator = (float)(((double)n1 * (double)n1) * (1.0 - (double)dt * (double)dt));
+  const float root = (float)sqrt(1.0 - ((double)numerator / ((double)n2 * (double)n2)));
+  const float s = n1 / n2;
+  const V3 a = s * (view - dt * n);
+  const V3 b = v3(n.x * root, n.y * root, n.z * root);
+  return normalized(a - b);
+}
+
 // wave64 compaction: returns this lane's slot in a global list, or ~0u when !want
 __device__ __forceinline__ uint32_t wave_alloc(bool want, uint32_t* counter, uint32_t per_item) {
   const unsigned long long m = __ballot(want);
@@ -401,72 +495,92 @@ __device__ __forceinline__ uint32_t wave_alloc(bool want, uint32_t* counter, uin
 }
 
 // Flyscene::traceRay miss branch + the ray-spawning half of Shader/calculateColor
-// (src/flyscene.cpp:587-601, 686-690, 723, 747-750).
-__global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs A) {
-  const uint32_t n = A.gen == 0 ? A.npix : *A.nrays;
+// (src/flyscene.cpp:587-601, 686-702, 704-712, 723, 747-750).
+__global__ __launch_bounds__(kBlock) void k_shade(PipeArgs A) {
+  const uint32_t n = A.nrays ? *A.nrays : A.n0;
   const uint32_t n_round = (n + 63u) & ~63u;    // whole waves enter the ballots
+  const uint32_t NLS = light_samples(A.S);
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_round; i += gridDim.x * kBlock) {
     const bool live = i < n;
-    RayRec r; r.valid = false; r.pixel = 0; r.thr = 0; r.o = v3(0, 0, 0); r.d1 = v3(0, 0, 0);
+    RayRec r; r.valid = false; r.pixel = 0; r.thr = 0; r.inside = false; r.o = v3(0, 0, 0); r.d1 = v3(0, 0, 0);
     float ht = INFINITY; int id = -1;
     if (live) {
-      r = load_ray(A.gen, A.C, A.rays, i);
+      r = load_node(A, i);
       const uint2 h = r.valid ? A.hits[i] : make_uint2(__float_as_uint(INFINITY), 0xFFFFFFFFu);
       ht = __uint_as_float(h.x); id = (int)h.y;
-      if (A.gen == 0 && r.valid) {
+      if (A.first_gen && r.valid) {
         if (A.out_t) A.out_t[i] = ht;
         if (A.out_face) A.out_face[i] = id >= 0 ? id : -1;
       }
     }
     const bool is_hit = live && (id != -1);
-    if (live && r.valid && !is_hit && A.gen == 0 && A.rgb) {
-      A.rgb[3 * (size_t)r.pixel] = (float)0.69019607843; A.rgb[3 * (size_t)r.pixel + 1] = 1.0f; A.rgb[3 * (size_t)r.pixel + 2] = 1.0f;
-    }
     if (!A.rgb) continue;   // hits only
+    if (live && r.valid && A.first_gen) {
+      // traceRay's miss colour at bounce 0 (src/flyscene.cpp:596-600); hit pixels start at 0 and
+      // receive their nodes' colours from k_resolve
+      float* px = A.rgb + 3 * (size_t)r.pixel;
+      const bool sky = !is_hit && A.bounce == 0;
+      px[0] = sky ? (float)0.69019607843 : 0.0f; px[1] = sky ? 1.0f : 0.0f; px[2] = sky ? 1.0f : 0.0f;
+    }
     const uint32_t slot = wave_alloc(is_hit, &A.counters[0], 1);
     Surface sf; sf.P = v3(0, 0, 0); sf.N = v3(0, 0, 0); sf.mat = -1;
-    float wr = 0.0f;
+    float wr = 0.0f, wt = 0.0f, ni = 0.0f;
     if (is_hit) {
       sf = surface_of(A.S, r.o, r.d1, ht, id);
       A.parents[slot] = i;
       if (A.shadows) {
-        for (uint32_t l = 0; l < A.S.nlights; ++l) {
-          const float4 L = A.S.lights[l];
+        for (uint32_t ls = 0; ls < NLS; ++ls) {
+          bool fifth;
+          const V3 L = light_sample(A, sf.P, ls, &fifth);
           // canSeeLight: Ray(position, toLight.normalized()) normalises twice (src/flyscene.cpp:749-750)
-          const V3 d1s = normalized(normalized(v3(L.x, L.y, L.z) - sf.P));
-          const size_t k = (size_t)slot * A.S.nlights + l;
+          const V3 d1s = normalized(normalized(L - sf.P));
+          const size_t k = (size_t)slot * NLS + ls;
           A.shadow_rays[2 * k] = make_float4(sf.P.x, sf.P.y, sf.P.z, 0.0f);
           A.shadow_rays[2 * k + 1] = make_float4(d1s.x, d1s.y, d1s.z, 0.0f);
         }
       }
-      wr = 1.0f - material_of(A.S, sf.mat).d;
+      if (A.gi_rays > 0) {
+        // Ray::resendRay (src/Ray.h:43-57): the reflected direction rotated about the normal
+        float m[9];
+        angle_axis_matrix(A.gi_sin, A.gi_cos, sf.N, m);
+        V3 dir = normalized(reflect_dir(r.d1, sf.N));
+        for (int k = 0; k < A.gi_rays; ++k) {
+          dir = mat3_mul(m, dir);
+          const V3 dn = normalized(dir);
+          const size_t q = (size_t)slot * (uint32_t)A.gi_rays + (uint32_t)k;
+          A.gi_q[2 * q] = make_float4(sf.P.x, sf.P.y, sf.P.z, 0.0f);
+          A.gi_q[2 * q + 1] = make_float4(dn.x, dn.y, dn.z, 0.0f);
+        }
+      }
+      const DevMat mat = material_of(A.S, sf.mat);
+      wr = 1.0f - mat.d; wt = mat.d; ni = mat.ni;
     }
-    const bool spawn = is_hit && A.reflection && (A.gen < A.max_bounces) && !(A.skip_zero_weight && wr == 0.0f);
-    const uint32_t rs = wave_alloc(spawn, &A.counters[1], 1);
-    if (spawn) {
-      // Ray::reflectRay(hit.normal, hit.point) (src/Ray.h:32-35)
-      const V3 nd = normalized(reflect_dir(r.d1, sf.N));
-      // every light's calculateColor adds (1 - d) * reflectedColor once (src/flyscene.cpp:611-614,744)
-      const float thr = r.thr * (wr * (float)A.S.nlights);
-      A.next_rays[2 * (size_t)rs] = make_float4(sf.P.x, sf.P.y, sf.P.z, __uint_as_float(r.pixel));
-      A.next_rays[2 * (size_t)rs + 1] = make_float4(nd.x, nd.y, nd.z, thr);
+    const bool deeper = is_hit && (A.bounce < A.max_bounces);
+    const bool spawn_r = deeper && A.reflection && !(A.skip_zero_weight && wr == 0.0f);
+    const bool spawn_t = deeper && A.refraction && !(A.skip_zero_weight && wt == 0.0f);
+    // every light's calculateColor adds (1-d)*reflected + d*refracted once (src/flyscene.cpp:611-626,744)
+    const float nl_tot = (float)(A.S.nlights + A.S.nsl);
+    const uint32_t rs = wave_alloc(spawn_r, &A.counters[1], 1);
+    if (spawn_r) {
+      const V3 nd = normalized(reflect_dir(r.d1, sf.N));            // Ray::reflectRay (src/Ray.h:32-35)
+      const uint32_t pw = r.pixel | (r.inside ? 0x80000000u : 0u);
+      A.next_rays[2 * (size_t)rs] = make_float4(sf.P.x, sf.P.y, sf.P.z, __uint_as_float(pw));
+      A.next_rays[2 * (size_t)rs + 1] = make_float4(nd.x, nd.y, nd.z, r.thr * (wr * nl_tot));
+    }
+    const uint32_t ts = wave_alloc(spawn_t, &A.counters[1], 1);
+    {
+      const unsigned long long mt = __ballot(spawn_t);       // refraction tally for the statistics
+      if (mt && (int)(threadIdx.x & 63) == __ffsll((long long)mt) - 1) atomicAdd(&A.counters[2], (uint32_t)__popcll(mt));
+    }
+    if (spawn_t) {
+      const V3 eye = normalized(r.o - sf.P);
+      const V3 nd = r.inside ? refract_dir(-sf.N, -eye, ni, 1.0f) : refract_dir(sf.N, -eye, 1.0f, ni);   // :691-701
+      const uint32_t pw = r.pixel | (r.inside ? 0u : 0x80000000u);
+      A.next_rays[2 * (size_t)ts] = make_float4(sf.P.x, sf.P.y, sf.P.z, __uint_as_float(pw));
+      A.next_rays[2 * (size_t)ts + 1] = make_float4(nd.x, nd.y, nd.z, r.thr * (wt * nl_tot));
     }
   }
 }
-
-struct ResolveArgs {
-  DevScene S;
-  DevCamera C;
-  int gen, shadows;
-  uint32_t npix;
-  const float4* rays;
-  const uint2* hits;
-  const uint32_t* parents;
-  const uint32_t* nparents;
-  const float4* shadow_rays;
-  const uint2* shadow_hits;
-  float* rgb;
-};
 
 // Flyscene::canSeeLight decision from the closest hit of the shadow ray (src/flyscene.cpp:752-781).
 // Returns visible; *bmat = blocker material id (-1: default Mtl).
@@ -487,36 +601,53 @@ __device__ __forceinline__ bool can_see_light(const DevScene& S, V3 light, V3 P,
   return (!sphere_block && ht == INFINITY) || behind;
 }
 
-// The local (non-recursive) part of Flyscene::calculateColor (src/flyscene.cpp:671-745), summed
-// over the point lights as Flyscene::Shader does (:611-614).
-__global__ __launch_bounds__(kBlock) void k_resolve(ResolveArgs A) {
-  const uint32_t n = *A.nparents;
+// The local (non-recursive) part of Flyscene::calculateColor (src/flyscene.cpp:671-745) summed
+// over the light samples as Flyscene::Shader does (:611-626), times the node's throughput.
+__global__ __launch_bounds__(kBlock) void k_resolve(PipeArgs A) {
+  const uint32_t n = A.counters[0];
+  const uint32_t NLS = light_samples(A.S);
   for (uint32_t h = blockIdx.x * kBlock + threadIdx.x; h < n; h += gridDim.x * kBlock) {
     const uint32_t i = A.parents[h];
-    const RayRec r = load_ray(A.gen, A.C, A.rays, i);
+    const RayRec r = load_node(A, i);
     const uint2 hh = A.hits[i];
     const Surface sf = surface_of(A.S, r.o, r.d1, __uint_as_float(hh.x), (int)hh.y);
     const DevMat mat = material_of(A.S, sf.mat);
-    const float I = 0.8f / (float)A.S.nlights;
+    const float I = 0.8f / (float)(A.S.nlights + A.S.nsl);
+    const V3 Iv = v3(I, I, I);
+    const V3 ka = v3(mat.ka[0], mat.ka[1], mat.ka[2]);
+    // global illumination term (src/flyscene.cpp:704-721), the same for every light
+    V3 gi = v3(0, 0, 0);
+    if (A.gi_rays > 0) {
+      for (int k = 0; k < A.gi_rays; ++k) {
+        const uint2 g = A.gi_hits[(size_t)h * (uint32_t)A.gi_rays + (uint32_t)k];
+        const float dist = __uint_as_float(g.x);
+        if (dist != 0.0f) {
+          const DevMat gm = material_of(A.S, (int)g.y);
+          const float fd = 50.0f * dist;
+          const double w = 1.0 / ((double)fd * (double)fd);
+          const float wf = (w < 1.0) ? (float)w : 1.0f;
+          gi = gi + v3(gm.kd[0] * wf, gm.kd[1] * wf, gm.kd[2] * wf);
+        }
+      }
+      gi = gi / (float)A.gi_rays;
+    }
     V3 total = v3(0, 0, 0);
-    for (uint32_t l = 0; l < A.S.nlights; ++l) {
-      const float4 Lp = A.S.lights[l];
-      const V3 light = v3(Lp.x, Lp.y, Lp.z);
+    const V3 eye = normalized(r.o - sf.P);
+    for (uint32_t ls = 0; ls < NLS; ++ls) {
+      bool fifth;
+      const V3 light = light_sample(A, sf.P, ls, &fifth);
       const V3 lightDir = normalized(light - sf.P);
       const V3 reflectedLight = reflect_dir(-lightDir, sf.N);
-      const V3 eye = normalized(r.o - sf.P);
       const float dotted = dot(eye, normalized(reflectedLight));
       bool visible = true; int bmat = -1;
       if (A.shadows) {
-        const size_t k = (size_t)h * A.S.nlights + l;
+        const size_t k = (size_t)h * NLS + ls;
         const float4 sd = A.shadow_rays[2 * k + 1];
         const uint2 sh = A.shadow_hits[k];
         visible = can_see_light(A.S, light, sf.P, v3(sd.x, sd.y, sd.z), __uint_as_float(sh.x), (int)sh.y, &bmat);
       }
-      const V3 Iv = v3(I, I, I);
-      const V3 ka = v3(mat.ka[0], mat.ka[1], mat.ka[2]);
       const float ndl = dot(sf.N, lightDir);
-      const float md = (ndl < 0.0f) ? 0.0f : ndl;
+      const float md = (ndl < 0.0f) ? 0.0f : ndl;          // std::max(a, b) = (a < b) ? b : a
       const float mdot = (dotted < 0.0f) ? 0.0f : dotted;
       V3 c;
       if (visible) {
@@ -524,7 +655,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(ResolveArgs A) {
         const V3 diffuse = md * cmul(v3(mat.kd[0], mat.kd[1], mat.kd[2]), Iv);
         const float sp = (float)pow((double)mdot, 33.0);
         const V3 specular = cmul(Iv, v3(mat.ks[0], mat.ks[1], mat.ks[2])) * sp;
-        c = (ambient + diffuse) + specular;
+        c = ((ambient + diffuse) + specular) + gi;
       } else {
         const DevMat bm = (bmat == -1) ? default_mtl() : material_of(A.S, bmat);
         const V3 ambientS = cmul(v3(bm.ka[0], bm.ka[1], bm.ka[2]), Iv);
@@ -534,11 +665,45 @@ __global__ __launch_bounds__(kBlock) void k_resolve(ResolveArgs A) {
         const V3 colorS = (ambientS + diffuseS) + specularS;
         c = cmul(ka, Iv) + colorS * bm.d;
       }
-      total = total + c;
+      total = total + (fifth ? c / 5.0f : c);
     }
     float* px = A.rgb + 3 * (size_t)r.pixel;
-    if (A.gen == 0) { px[0] = total.x; px[1] = total.y; px[2] = total.z; }
-    else { px[0] += r.thr * total.x; px[1] += r.thr * total.y; px[2] += r.thr * total.z; }
+    const V3 add = v3(r.thr * total.x, r.thr * total.y, r.thr * total.z);
+    if (A.atomic_accum) { atomicAdd(px, add.x); atomicAdd(px + 1, add.y); atomicAdd(px + 2, add.z); }
+    else { px[0] += add.x; px[1] += add.y; px[2] += add.z; }
+  }
+}
+
+// Flyscene::trace_global_illum (src/flyscene.cpp:631-669): spheres, then the reference's flat
+// leaf-box list (slab gate per leaf, that leaf's own triangle list, strict < in list order).
+// Deliberately NOT the BVH: the leaf lists are lossy and the colour depends on it.
+__global__ __launch_bounds__(kBlock) void k_trace_gi(DevScene S, const float4* rays, const uint32_t* count, uint32_t stride,
+                                                   uint2* out) {
+  const uint32_t n = *count * stride;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float4 ro = rays[2 * (size_t)i], rd = rays[2 * (size_t)i + 1];
+    const V3 o = v3(ro.x, ro.y, ro.z), d1 = v3(rd.x, rd.y, rd.z);
+    float smallest = INFINITY; int mat = -1;
+    for (uint32_t s = 0; s < S.nspheres; ++s) {
+      const float t = ref_sphere_t(o, d1, S.spheres[s]);
+      if (t != INFINITY && t < smallest) { smallest = t; mat = S.sph_mat[s]; }
+    }
+    const V3 d = normalized(d1);
+    for (uint32_t b = 0; b < S.nleafboxes; ++b) {
+      const float4 lo = S.leafboxes[2 * b], hi = S.leafboxes[2 * b + 1];
+      const float blo[3] = {lo.x, lo.y, lo.z}, bhi[3] = {hi.x, hi.y, hi.z};
+      if (ref_box_t(o, d, blo, bhi) != INFINITY) {
+        Hit best; best.t = INFINITY; best.id = -1;
+        const uint32_t start = __float_as_uint(lo.w), cnt = __float_as_uint(hi.w);
+        for (uint32_t k = 0; k < cnt; ++k) {
+          Hit one; one.t = INFINITY; one.id = -1;
+          test_triangle(S, (uint32_t)S.face_pos[S.leaf_faces[start + k]], o, d, &one);
+          if (one.t < best.t) best = one;             // intersectTriangle: strict < in list order
+        }
+        if (best.t != INFINITY && smallest > best.t) { smallest = best.t; mat = __float_as_int(S.face_nm[best.id].w); }
+      }
+    }
+    out[i] = (smallest != INFINITY) ? make_uint2(__float_as_uint(smallest), (uint32_t)mat) : make_uint2(0u, 0xFFFFFFFFu);
   }
 }
 

@@ -1,0 +1,465 @@
+// Host-side mirror of the reference's ray-tracing surface over the C ABI (include/rtx.h).
+//
+// Same class and method names, argument meaning and miss/error behaviour as
+//   Flyscene  (src/flyscene.hpp:30-221)      Scene   (src/Scene.h:18-78)
+//   Ray       (src/Ray.h:7-58)               HitInfo (src/hitInfo.h:4-16)
+//   Box       (src/box.h:8-97)               Tucano::Face / Material::Mtl / Flycamera (the parts the tracer reads)
+// so that callers of the reference (src/main.cpp:63-77) compile against this header
+// instead.  Every query is forwarded to the GPU library; nothing here intersects or
+// shades on the CPU.  GL preview, debug-ray drawing and GLFW input are out of scope.
+//
+// Vector types: a small Vector3f with the Eigen spelling the callers use (x(), y(), z(),
+// operator[], + - *, dot, norm, normalized).  Eigen itself is not a dependency.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <ctime>
+#include <chrono>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/rtx.h"
+
+namespace rtxhost {
+
+struct Vector3f {
+  float v[3];
+  Vector3f() : v{0, 0, 0} {}
+  Vector3f(float x, float y, float z) : v{x, y, z} {}
+  float x() const { return v[0]; }
+  float y() const { return v[1]; }
+  float z() const { return v[2]; }
+  float& operator[](int i) { return v[i]; }
+  float operator[](int i) const { return v[i]; }
+  Vector3f operator+(const Vector3f& o) const { return Vector3f(v[0] + o.v[0], v[1] + o.v[1], v[2] + o.v[2]); }
+  Vector3f operator-(const Vector3f& o) const { return Vector3f(v[0] - o.v[0], v[1] - o.v[1], v[2] - o.v[2]); }
+  Vector3f operator-() const { return Vector3f(-v[0], -v[1], -v[2]); }
+  Vector3f operator*(float s) const { return Vector3f(v[0] * s, v[1] * s, v[2] * s); }
+  Vector3f operator/(float s) const { return Vector3f(v[0] / s, v[1] / s, v[2] / s); }
+  Vector3f& operator+=(const Vector3f& o) { *this = *this + o; return *this; }
+  // Eigen evaluation order (Redux.h:91-103, Dot.h:124-134)
+  float dot(const Vector3f& o) const { return v[0] * o.v[0] + (v[1] * o.v[1] + v[2] * o.v[2]); }
+  float squaredNorm() const { return dot(*this); }
+  float norm() const { return std::sqrt(squaredNorm()); }
+  Vector3f normalized() const { float z = squaredNorm(); return z > 0.0f ? *this / std::sqrt(z) : *this; }
+  Vector3f cross(const Vector3f& o) const {
+    return Vector3f(v[1] * o.v[2] - v[2] * o.v[1], v[2] * o.v[0] - v[0] * o.v[2], v[0] * o.v[1] - v[1] * o.v[0]);
+  }
+  Vector3f cwiseProduct(const Vector3f& o) const { return Vector3f(v[0] * o.v[0], v[1] * o.v[1], v[2] * o.v[2]); }
+};
+inline Vector3f operator*(float s, const Vector3f& a) { return Vector3f(s * a.v[0], s * a.v[1], s * a.v[2]); }
+struct Vector2f { float v[2]; Vector2f(float a = 0, float b = 0) : v{a, b} {} float operator[](int i) const { return v[i]; } };
+struct Vector2i { int v[2]; Vector2i(int a = 0, int b = 0) : v{a, b} {} int& operator[](int i) { return v[i]; } int operator[](int i) const { return v[i]; } };
+struct Vector4f { float v[4]; Vector4f(float a = 0, float b = 0, float c = 0, float d = 0) : v{a, b, c, d} {}
+  float w() const { return v[3]; } Vector3f head3() const { return Vector3f(v[0], v[1], v[2]); } };
+
+struct RtxError : std::runtime_error { int code; RtxError(int c, const std::string& m) : std::runtime_error(m), code(c) {} };
+inline int rtx_check(int rc) { if (rc < 0) throw RtxError(rc, std::string("rtx: ") + rtx_last_error()); return rc; }
+
+namespace Tucano {
+// tucano/mesh.hpp:238-247
+class Face { public: std::vector<unsigned> vertex_ids; int material_id = -1; Vector3f normal; };
+namespace Material {
+// tucano/materials/mtl.hpp:16-116
+class Mtl {
+ public:
+  Vector3f ka{0.3f, 0.3f, 0.3f}, kd{0.5f, 0.5f, 0.5f}, ks{1.0f, 1.0f, 1.0f};
+  float shininess = 10, optical_density = 0.0f, dissolve_factor = 1.0f;
+  int illumination_model = 0;
+  std::string name;
+  void setAmbient(Vector3f v) { ka = v; } void setDiffuse(Vector3f v) { kd = v; } void setSpecular(Vector3f v) { ks = v; }
+  void setShininess(float v) { shininess = v; } void setOpticalDensity(float v) { optical_density = v; }
+  void setDissolveFactor(float v) { dissolve_factor = v; } void setIlluminationModel(int v) { illumination_model = v; }
+  void setName(std::string n) { name = n; } std::string getName() { return name; }
+  Vector3f getDiffuse() const { return kd; } Vector3f getAmbient() const { return ka; } Vector3f getSpecular() const { return ks; }
+  float getShininess() const { return shininess; } float getOpticalDensity() const { return optical_density; }
+  float getDissolveFactor() const { return dissolve_factor; } float getIlluminationModel() const { return (float)illumination_model; }
+  rtx_material raw() const {
+    rtx_material m;
+    for (int k = 0; k < 3; ++k) { m.ka[k] = ka[k]; m.kd[k] = kd[k]; m.ks[k] = ks[k]; }
+    m.ns = shininess; m.ni = optical_density; m.d = dissolve_factor; m.illum = illumination_model;
+    return m;
+  }
+};
+}  // namespace Material
+
+// The state of Tucano::Flycamera the tracer reads (tucano/utils/flycamera.hpp:76-86,166-191,
+// tucano/camera.hpp:42-78).  The view matrix is kept as [R|t]; yaw/pitch composition follows
+// updateViewMatrix (rows = rotated X, Y, Z axes, then translate(default) and translate(user)).
+class Flycamera {
+ public:
+  float view[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, -2};   // identity rotation, default translation (0,0,-2)
+  float viewport[4] = {0, 0, 1, 1};
+  float fovy = 60.0f, aspect_ratio = 1.0f;
+  void setPerspectiveMatrix(float fy, float aspect, float /*near*/, float /*far*/) { fovy = fy; aspect_ratio = aspect; }
+  void setViewport(const Vector2f& vp) { viewport[0] = 0; viewport[1] = 0; viewport[2] = vp[0]; viewport[3] = vp[1]; }
+  Vector2i getViewportSize() const { return Vector2i((int)viewport[2], (int)viewport[3]); }
+  void setViewMatrix(const float m34[12]) { for (int i = 0; i < 12; ++i) view[i] = m34[i]; }
+  rtx_camera raw() const {
+    rtx_camera c;
+    for (int i = 0; i < 12; ++i) c.view[i] = view[i];
+    for (int i = 0; i < 4; ++i) c.viewport[i] = viewport[i];
+    c.fovy = fovy; c.aspect = aspect_ratio; c.subpixel[0] = c.subpixel[1] = 0.0f;
+    return c;
+  }
+};
+}  // namespace Tucano
+
+// src/hitInfo.h:4-16
+struct HitInfo { float t; int faceId; Vector3f normal; Vector3f point; };
+
+// src/Ray.h:7-35 (construction normalises; reflectRay as the tracer uses it)
+class Ray {
+  Vector3f origin, dir;
+ public:
+  Ray(Vector3f _origin, Vector3f _dir) { origin = _origin; dir = _dir.normalized(); }
+  Vector3f getOrigin() { return origin; }
+  Vector3f getDirection() { return dir; }
+  Vector3f getPointOnRay(float t) { return Vector3f(origin[0] + t * dir[0], origin[1] + t * dir[1], origin[2] + t * dir[2]); }
+  Ray reflectRay(Vector3f normal, Vector3f point) {
+    Vector3f newDir = dir - (2.0f * dir.dot(normal)) * normal;
+    return Ray(point, newDir);
+  }
+};
+
+// src/box.h:8-97 (value type; the GPU hierarchy lives inside librtx)
+class Box {
+ public:
+  Vector3f tmax, tmin;
+  std::vector<Tucano::Face> triangles;
+  std::vector<Box> children;
+  Box() {}
+  Box(Vector3f tmin_, Vector3f tmax_) { tmin = tmin_; tmax = tmax_; }
+  bool isInBox(Vector3f o) {
+    return (o.x() >= tmin.x() && o.x() <= tmax.x()) && (o.y() >= tmin.y() && o.y() <= tmax.y()) && (o.z() >= tmin.z() && o.z() <= tmax.z());
+  }
+};
+
+// src/Scene.h:18-78: the analytic sphere list
+class Scene {
+ public:
+  struct SphereRec { Vector3f center; float radius; int material_id; };
+  std::vector<SphereRec> spheres;
+  static constexpr float RADIUS_CORRECTION = 3.0f;      // src/Scene.h:11
+  Tucano::Material::Mtl addSphere(Vector3f center, float radius, Vector3f color) {
+    spheres.push_back({center, radius / RADIUS_CORRECTION, -1});
+    Tucano::Material::Mtl m;
+    m.setAmbient(color / 3.0f); m.setDiffuse(color); m.setSpecular(Vector3f(0.5f, 0.5f, 0.5f));
+    m.setIlluminationModel(2); m.setShininess(10); m.setDissolveFactor(0); m.setOpticalDensity(1);
+    return m;
+  }
+  int getNumberOfSpheres() { return (int)spheres.size(); }
+  SphereRec& getSphere(int i) { return spheres[i]; }
+};
+
+// ---- OBJ + MTL import with Tucano's face order (tucano/utils/objimporter.hpp:83-284,
+// tucano/utils/mtlIO.hpp:45-125, tucano/mesh.hpp:441-468) and the P3 writer (tucano/utils/ppmIO.hpp:130-151)
+struct MeshData {
+  std::vector<float> verts;
+  std::vector<uint32_t> idx;
+  std::vector<int32_t> tri_mat;
+};
+inline bool loadMTL(std::vector<Tucano::Material::Mtl>& materials, const std::string& filename) {
+  std::ifstream in(filename.c_str());
+  if (!in) { std::cerr << "Cannot open " << filename << std::endl; return false; }
+  for (std::string line; std::getline(in, line);) {
+    if (line.empty()) continue;
+    std::stringstream ss(line);
+    std::vector<std::string> tok;
+    for (std::string s; std::getline(ss, s, ' ');) tok.push_back(s);
+    if (tok.empty()) continue;
+    auto T = [&](size_t i) { return i < tok.size() ? tok[i].c_str() : ""; };
+    if (tok[0] == "#") continue;
+    if (tok[0] == "newmtl") { materials.emplace_back(); materials.back().setName(T(1)); }
+    else if (materials.empty()) continue;
+    else if (tok[0] == "Ns") materials.back().setShininess((float)atof(T(1)));
+    else if (tok[0] == "Ka") materials.back().setAmbient(Vector3f((float)atof(T(1)), (float)atof(T(2)), (float)atof(T(3))));
+    else if (tok[0] == "Kd") materials.back().setDiffuse(Vector3f((float)atof(T(1)), (float)atof(T(2)), (float)atof(T(3))));
+    else if (tok[0] == "Ks") materials.back().setSpecular(Vector3f((float)atof(T(1)), (float)atof(T(2)), (float)atof(T(3))));
+    else if (tok[0] == "Ni") materials.back().setOpticalDensity((float)atof(T(1)));
+    else if (tok[0] == "d") materials.back().setDissolveFactor((float)atof(T(1)));
+    else if (tok[0] == "illum") materials.back().setIlluminationModel(atoi(T(1)));
+  }
+  if (materials.empty()) materials.emplace_back();
+  return true;
+}
+inline bool loadObjFile(MeshData& mesh, std::vector<Tucano::Material::Mtl>& mtls, const std::string& filename) {
+  std::ifstream in(filename.c_str());
+  if (!in) { std::cerr << "Cannot open " << filename << std::endl; return false; }   // the reference exit(1)s here
+  std::string path;
+  size_t slash = filename.find_last_of('/');
+  if (slash != std::string::npos) path = filename.substr(0, slash + 1);
+  std::vector<std::vector<uint32_t>> groups(1);
+  std::vector<int> group_mat(1, -1);
+  int current_mat = -1;
+  for (std::string line; std::getline(in, line);) {
+    if (line.compare(0, 6, "mtllib") == 0) {
+      std::string fn = path + (line.size() > 7 ? line.substr(7) : "");
+      std::string clean;
+      for (char c : fn) if (c != '\n' && c != '\r') clean.push_back(c);
+      loadMTL(mtls, clean);
+    } else if (line.compare(0, 6, "usemtl") == 0) {
+      if (!groups.back().empty()) { groups.emplace_back(); group_mat.push_back(-1); }
+      std::string name = line.size() > 7 ? line.substr(7) : "";
+      for (size_t i = 0; i < mtls.size(); ++i) if (mtls[i].getName() == name) current_mat = (int)i;
+      group_mat.back() = current_mat;
+    } else if (line.compare(0, 2, "v ") == 0) {
+      std::istringstream s(line.substr(2));
+      float x = 0, y = 0, z = 0;
+      s >> x; s >> y; s >> z;
+      mesh.verts.push_back(x); mesh.verts.push_back(y); mesh.verts.push_back(z);
+    } else if (line.compare(0, 2, "f ") == 0) {
+      std::stringstream ls(line.substr(2));
+      for (std::string e; ls >> e;) groups.back().push_back((uint32_t)(atoi(e.c_str()) - 1));
+    }
+  }
+  for (size_t g = 0; g < groups.size(); ++g)
+    for (size_t i = 0; i + 2 < groups[g].size(); i += 3) {
+      mesh.idx.push_back(groups[g][i]); mesh.idx.push_back(groups[g][i + 1]); mesh.idx.push_back(groups[g][i + 2]);
+      mesh.tri_mat.push_back(group_mat[g]);
+    }
+  return true;
+}
+inline void writePPMImage(const std::string& filename, const std::vector<std::vector<Vector3f>>& data) {
+  int width = (int)data[0].size(), height = (int)data.size();
+  std::ofstream out(filename.c_str());
+  out << "P3\n" << width << " " << height << "\n255\n";
+  for (int j = 0; j < height; ++j) {
+    for (int i = 0; i < width; ++i)
+      out << std::min(255, (int)(255 * data[i][j][0])) << " " << std::min(255, (int)(255 * data[i][j][1])) << " "
+          << std::min(255, (int)(255 * data[i][j][2])) << " ";
+    out << "\n";
+  }
+}
+
+// ---- Flyscene (src/flyscene.hpp:30-221), ray-tracing half
+class Flyscene {
+ public:
+  std::string model_path = "resources/models/planeobj.obj";     // src/flyscene.cpp:22-23
+  int device = 0;
+  // the reference's compile-time switches (src/flyscene.cpp:11,704): {MAX_BOUNCES 2, reflect, refract, 8 GI, shadows}
+  rtx_options options{2, 1, 1, 8, 1, 0};
+  Box root_box;                                                  // src/flyscene.hpp:219
+
+  Flyscene() {}
+  ~Flyscene() { if (scene) rtx_scene_destroy(scene); }
+  Flyscene(const Flyscene&) = delete;
+  Flyscene& operator=(const Flyscene&) = delete;
+
+  // src/flyscene.cpp:13-120 without the GL parts
+  void initialize(int width, int height) {
+    flycamera.setPerspectiveMatrix(60.0f, width / (float)height, 0.1f, 100.0f);
+    flycamera.setViewport(Vector2f((float)width, (float)height));
+    mesh = MeshData(); materials.clear();
+    if (!loadObjFile(mesh, materials, model_path)) throw RtxError(RTX_EINVAL, "cannot open " + model_path);
+    mesh_materials = materials.size();
+    lights.clear(); sphericalLights.clear();
+    lights.push_back(Vector3f(-1.0f, 1.0f, 1.0f));             // :48
+    spheres_added = false; currentScene = Scene();
+    rebuild();
+  }
+  Tucano::Flycamera* getCamera() { return &flycamera; }
+  void addLight() { lights.push_back(getCenter()); dirty = true; }                       // src/flyscene.hpp:61
+  void addSphericalLight() { sphericalLights.push_back({getCenter(), 0.01f}); dirty = true; }   // :62
+  int getNumberOfFaces() const { return (int)mesh.tri_mat.size(); }
+
+  // src/flyscene.cpp:395-439
+  void raytraceScene(int width = 0, int height = 0) {
+    std::cout << "ray tracing ..." << std::endl;
+    auto t0 = std::chrono::steady_clock::now();
+    Vector2i image_size(width, height);
+    if (width == 0 || height == 0) image_size = flycamera.getViewportSize();
+    std::vector<std::vector<Vector3f>> pixel_data(image_size[1]);
+    for (int i = 0; i < image_size[1]; ++i) pixel_data[i].resize(image_size[0]);
+    Vector3f origin = getCenter();
+    updating_pixels(pixel_data, origin, image_size, 1, 0);       // one GPU frame instead of 16 racing threads
+    writePPMImage("result.ppm", pixel_data);
+    auto ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    std::cout << "Time elapsed: " << (long)ms << " ms" << std::endl << "ray tracing done! " << std::endl;
+  }
+
+  // src/flyscene.cpp:441-468.  Rows thread_id, thread_id + number_threads, ... of the frame are
+  // written to pixel_data[i][j] (the reference's [x][y] indexing).  The spheres are
+  // added once, not once per thread.
+  void updating_pixels(std::vector<std::vector<Vector3f>>& pixel_data, Vector3f& /*origin*/, Vector2i& image_size,
+                       int number_threads, int thread_id) {
+    if (!spheres_added) add_reference_spheres();
+    sync();
+    const int W = image_size[0], H = image_size[1];
+    if (frame_w != W || frame_h != H || frame_dirty) {
+      frame.resize((size_t)W * H * 3);
+      rtx_camera cam = flycamera.raw();
+      rtx_rect r{0, 0, W, H};
+      rtx_check(rtx_render(scene, &cam, &options, r, frame.data(), nullptr, nullptr));
+      frame_w = W; frame_h = H; frame_dirty = false;
+    }
+    for (int j = thread_id; j < H; j += number_threads)
+      for (int i = 0; i < W; ++i) {
+        const float* p = &frame[3 * ((size_t)j * W + i)];
+        pixel_data[i][j] = Vector3f(p[0], p[1], p[2]);
+      }
+  }
+
+  // src/flyscene.cpp:587-601
+  Vector3f traceRay(int bounce, Ray ray, bool insideObject) {
+    sync();
+    Vector3f o = ray.getOrigin(), d = ray.getDirection(), c;
+    rtx_check(rtx_trace_shade(scene, &options, o.v, d.v, 1, bounce, insideObject ? 1 : 0, c.v));
+    return c;
+  }
+  // src/flyscene.cpp:517-585
+  std::pair<HitInfo, Tucano::Face> getIntersections(Ray ray) {
+    sync();
+    Vector3f o = ray.getOrigin(), d = ray.getDirection();
+    HitInfo h; int mat = -1;
+    rtx_check(rtx_trace_closest(scene, o.v, d.v, 1, &h.t, &h.faceId, h.normal.v, h.point.v, &mat));
+    Tucano::Face f;
+    if (h.faceId >= 0) f = make_face(h.faceId);
+    f.material_id = mat;
+    return std::make_pair(h, f);
+  }
+  // src/flyscene.cpp:819-879: closest triangle of a face list; faceId indexes that list.
+  HitInfo intersectTriangle(std::vector<Tucano::Face>& faces, Vector3f origin, Vector3f dir) {
+    std::vector<uint32_t> idx; idx.reserve(faces.size() * 3);
+    for (auto& f : faces) for (int k = 0; k < 3; ++k) idx.push_back(f.vertex_ids[k]);
+    rtx_scene* tmp = nullptr;
+    rtx_check(rtx_scene_create(mesh.verts.data(), (uint32_t)(mesh.verts.size() / 3), idx.data(), nullptr, (uint32_t)faces.size(),
+                               nullptr, 0, &tmp));
+    HitInfo h{INFINITY, -1, Vector3f(), Vector3f()};
+    int rc = rtx_scene_set_flags(tmp, RTX_FLAG_NO_ROOT_GATE);
+    if (rc >= 0) rc = rtx_scene_commit(tmp, device);
+    if (rc >= 0) rc = rtx_trace_closest(tmp, origin.v, dir.v, 1, &h.t, &h.faceId, h.normal.v, h.point.v, nullptr);
+    std::string err = rc < 0 ? rtx_last_error() : "";
+    rtx_scene_destroy(tmp);
+    if (rc < 0) throw RtxError(rc, "rtx: " + err);
+    return h;
+  }
+  // src/flyscene.cpp:906-972
+  HitInfo intersectBox(Box& box, Vector3f origin, Vector3f dest) {
+    sync();
+    HitInfo h{INFINITY, -1, Vector3f(), Vector3f()};
+    rtx_check(rtx_intersect_box(scene, box.tmin.v, box.tmax.v, origin.v, dest.v, 1, &h.t));
+    return h;
+  }
+  // src/flyscene.cpp:747-782
+  std::pair<bool, Tucano::Material::Mtl> canSeeLight(Vector3f lightPos, Vector3f position) {
+    sync();
+    uint8_t vis = 0; int bm = -1;
+    rtx_check(rtx_trace_visible(scene, lightPos.v, position.v, 1, &vis, &bm));
+    Tucano::Material::Mtl m;
+    if (bm >= 0 && bm < (int)materials.size()) m = materials[bm];
+    return std::make_pair(vis != 0, m);
+  }
+  Vector3f getCenter() {
+    sync();
+    rtx_camera cam = flycamera.raw();
+    Vector3f c;
+    rtx_check(rtx_camera_points(scene, &cam, nullptr, 0, nullptr, c.v));
+    return c;
+  }
+  Vector3f screenToWorld(const Vector2f& p) {
+    sync();
+    rtx_camera cam = flycamera.raw();
+    Vector3f w;
+    rtx_check(rtx_camera_points(scene, &cam, p.v, 1, w.v, nullptr));
+    return w;
+  }
+  const rtx_stats& lastStats() { rtx_get_stats(scene, &stats); return stats; }
+  void markCameraChanged() { frame_dirty = true; }
+
+  std::vector<Vector3f> lights;
+  std::vector<std::pair<Vector3f, float>> sphericalLights;
+  std::vector<Tucano::Material::Mtl> materials;
+  Scene currentScene;
+
+  // src/flyscene.hpp:177-206
+  std::vector<Vector4f> spherePositions{
+      {-0.5f * 0.5f, 0.25f * 0.5f, 0.8f * 0.5f, 0.75f * 0.5f}, {0.75f * 0.5f, 0.25f * 0.5f, 0.7f * 0.5f, 0.75f * 0.5f},
+      {0.6f * 0.5f, 0.25f * 0.5f, -0.4f * 0.5f, 0.75f * 0.5f}, {-0.45f * 0.5f, 0.25f * 0.5f, -0.4f * 0.5f, 0.75f * 0.5f},
+      {0.0f * 0.5f, 0.167f * 0.5f, 1.2f * 0.5f, 0.5f * 0.5f}, {1.0f * 0.5f, 0.167f * 0.5f, 1.2f * 0.5f, 0.5f * 0.5f},
+      {-1.0f * 0.5f, 0.25f * 0.5f, 1.2f * 0.5f, 0.75f * 0.5f}, {0.0f * 0.5f, 0.33f * 0.5f, -2.2f * 0.5f, 1.0f * 0.5f},
+      {0.0f * 0.5f, 0.33f * 0.5f, 2.2f * 0.5f, 1.0f * 0.5f}, {-3.0f * 0.5f, 0.167f * 0.5f, -2.2f * 0.5f, 0.5f * 0.5f},
+      {3.0f * 0.5f, 0.25f * 0.5f, -2.2f * 0.5f, 0.75f * 0.5f}, {3.5f * 0.5f, 0.33f * 0.5f, 0.0f * 0.5f, 1.0f * 0.5f},
+      {-3.5f * 0.5f, 0.167f * 0.5f, 0.0f * 0.5f, 0.5f * 0.5f}};
+  std::vector<Vector3f> sphereColors{
+      {0.8f, 0.2401f, 0.0f}, {0.5f, 0.5f, 0}, {(float)0.98824, (float)0.72941, (float)0.01176}, {0.0f, 0.5f, 0.5f},
+      {1.0f, 0.0f, 1.0f}, {1.0f, 0.75f, 1.0f}, {0.5f, 1.0f, 0.75f}, {0.4f, 0.3f, 1.0f}, {0.8f, 0.667f, 0.0f},
+      {1.0f, 0.75f, 1.0f}, {0.0f, 0.7f, 1.0f}, {1.0f, 0.5f, 0.3f}, {0.0f, 0.3f, 0.123f}};
+
+ private:
+  Tucano::Flycamera flycamera;
+  MeshData mesh;
+  size_t mesh_materials = 0;
+  rtx_scene* scene = nullptr;
+  bool dirty = true, spheres_added = false, frame_dirty = true;
+  std::vector<float> frame;
+  int frame_w = 0, frame_h = 0;
+  rtx_stats stats{};
+
+  Tucano::Face make_face(int f) {
+    Tucano::Face face;
+    for (int k = 0; k < 3; ++k) face.vertex_ids.push_back(mesh.idx[3 * (size_t)f + k]);
+    face.material_id = mesh.tri_mat[f];
+    return face;
+  }
+  void rebuild() {
+    if (scene) { rtx_scene_destroy(scene); scene = nullptr; }
+    std::vector<rtx_material> raw;
+    for (size_t i = 0; i < mesh_materials; ++i) raw.push_back(materials[i].raw());
+    rtx_check(rtx_scene_create(mesh.verts.data(), (uint32_t)(mesh.verts.size() / 3), mesh.idx.data(), mesh.tri_mat.data(),
+                               (uint32_t)mesh.tri_mat.size(), raw.data(), (uint32_t)raw.size(), &scene));
+    pushed_materials = mesh_materials;
+    // Box(mesh) + divideBox_KD(sqrt(F + 100)) (src/flyscene.cpp:77-82): the leaf list the GI probes walk
+    int leaves = rtx_scene_build_reference_leafboxes(scene, 0, 0);
+    if (leaves < 0) { std::cerr << "warning: " << rtx_last_error() << "; global illumination probes disabled" << std::endl; options.gi_rays = 0; }
+    root_box.triangles.clear();
+    for (int f = 0; f < (int)mesh.tri_mat.size(); ++f) root_box.triangles.push_back(make_face(f));
+    dirty = true;
+    sync();
+    rtx_scene_info info;
+    rtx_check(rtx_scene_get_info(scene, &info));
+    std::cout << "Number of leafs: " << leaves << std::endl;
+  }
+  // src/flyscene.cpp:452-458, once
+  void add_reference_spheres() {
+    if (spherePositions.size() != sphereColors.size()) abort();
+    for (size_t i = 0; i < spherePositions.size(); i++) {
+      auto tempMat = currentScene.addSphere(spherePositions[i].head3(), spherePositions[i].w(), sphereColors[i]);
+      int mat_id = (int)materials.size();
+      materials.push_back(tempMat);
+      currentScene.getSphere((int)i).material_id = mat_id;
+    }
+    spheres_added = true; dirty = true;
+  }
+  // push lights / spheres / appended materials and (re)commit when something changed
+  void sync() {
+    if (!dirty) return;
+    rtx_scene_info info{};
+    std::vector<float> L, SL, S;
+    std::vector<int32_t> SM;
+    for (auto& l : lights) { L.push_back(l[0]); L.push_back(l[1]); L.push_back(l[2]); }
+    for (auto& s : sphericalLights) { SL.push_back(s.first[0]); SL.push_back(s.first[1]); SL.push_back(s.first[2]); SL.push_back(s.second); }
+    for (auto& s : currentScene.spheres) { S.push_back(s.center[0]); S.push_back(s.center[1]); S.push_back(s.center[2]); S.push_back(s.radius); SM.push_back(s.material_id); }
+    rtx_check(rtx_scene_set_lights(scene, L.data(), (uint32_t)lights.size(), SL.data(), (uint32_t)sphericalLights.size()));
+    rtx_check(rtx_scene_set_spheres(scene, S.data(), SM.data(), (uint32_t)SM.size()));
+    rtx_check(rtx_scene_build(scene));
+    rtx_check(rtx_scene_get_info(scene, &info));
+    // materials appended after the MTL ones (sphere materials, src/flyscene.cpp:455-456)
+    while (pushed_materials < materials.size()) {
+      rtx_material m = materials[pushed_materials].raw();
+      rtx_check(rtx_scene_add_material(scene, &m));
+      ++pushed_materials;
+    }
+    rtx_check(rtx_scene_commit(scene, device));
+    dirty = false; frame_dirty = true;
+  }
+  size_t pushed_materials = 0;
+};
+
+}  // namespace rtxhost

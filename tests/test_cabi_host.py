@@ -145,3 +145,25 @@ def test_empty_and_degenerate_scenes_build(api):
     nodes, order = s.bvh()
     assert s.info().nwild == 3          # zero-area faces never enter the hierarchy
     _check_bvh(nodes, order, 3, 3)
+
+
+@pytest.mark.parametrize("name,leaves", [("planeobj", 4), ("cube", 2), ("twoObjects", 1), ("plane", 1), ("toy", 241)])
+def test_reference_leaf_list_matches_oracle(api, oa, name, leaves):
+    """librtx's divideBox_KD restatement (product side) == the oracle's == SURVEY F13 counts."""
+    fx = load_scene_fixture(name)
+    s = api.Scene(fx["verts"], fx["idx"], fx["tri_mat"], rtx_materials(fx["mats"]))
+    assert s.build_reference_leafboxes() == leaves
+    o = oa.Scene(fx["verts"], fx["idx"], fx["tri_mat"], oracle_materials(fx["mats"]))
+    assert o.build_leafboxes() == leaves
+    for (lo, hi, faces), (olo, ohi, ofaces) in zip(s.leafboxes(), o.leaves()):
+        assert_bits_equal(lo, olo, "leaf min")
+        assert_bits_equal(hi, ohi, "leaf max")
+        assert np.array_equal(faces, ofaces)
+
+
+@pytest.mark.parametrize("name", ["test", "spheres", "dodgeColorTest"])
+def test_reference_leaf_list_nontermination_is_reported(api, name):
+    fx = load_scene_fixture(name)
+    s = api.Scene(fx["verts"], fx["idx"], fx["tri_mat"], rtx_materials(fx["mats"]))
+    with pytest.raises(api.RtxError, match="does not terminate"):
+        s.build_reference_leafboxes()
