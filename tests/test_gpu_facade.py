@@ -51,7 +51,7 @@ def test_facade_matches_oracle(tmp_path, oa):
     out = subprocess.run([DEMO, base + ".obj", str(W), base + ".rays"], cwd=str(tmp_path), capture_output=True, text=True,
                          timeout=300)
     assert out.returncode == 0, out.stderr
-    lines = [l.split() for l in out.stdout.splitlines()]
+    lines = [l.split() for l in out.stdout.splitlines() if l.strip()]
     assert ["faces", "14", "materials", "2"] in lines
     assert [l for l in lines if l[0] == "center"][0][1:] == ["0", "0", "2"]
 
@@ -69,7 +69,8 @@ def test_facade_matches_oracle(tmp_path, oa):
     h = o.closest(org, d1)
     rgb = o.trace(org, d1)
     vis, bm, _, _ = o.visible(np.tile(np.float32([-1, 1, 1]), (n, 1)), h["p"])
-    it = iter(lines[2:])
+    start = max(i for i, l in enumerate(lines) if l and l[0] == "center") + 1
+    it = iter(lines[start:])
     f32 = lambda xs: np.array([float(x) for x in xs], np.float32)
     for i in range(n):
         l = next(it)
