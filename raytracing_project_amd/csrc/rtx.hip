@@ -91,6 +91,9 @@ struct rtx_scene {
   DevBuf d_nodes, d_tris, d_tri_face, d_face_nm, d_spheres, d_sph_mat, d_mats, d_lights;
   DevBuf d_slights, d_leafboxes, d_leaf_faces, d_face_pos;
   // workspace
+  DevBuf w_cursors;                  // one work cursor per traversal launch of a call (zeroed in stats_begin)
+  DevBuf w_stack_ovf;                // global overflow columns of the per-lane traversal stacks
+  uint32_t cursors_used = 0;
   DevBuf w_rays[2], w_hits[2], w_parents, w_shadow_rays, w_shadow_hits, w_gi_rays, w_gi_hits, w_counters, w_io[6];
   EventPool events;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_spans, all_spans;
@@ -99,6 +102,8 @@ struct rtx_scene {
   rtx_scene_info info{};
   int ncu = 256;
 };
+
+static int trace_grid(const rtx_scene* s) { return s->ncu * 8; }      // 8 blocks x 4 waves = 32 waves per CU
 
 extern "C" const char* rtx_last_error(void) { return g_err.c_str(); }
 
@@ -128,7 +133,7 @@ static void release_device(rtx_scene* s) {
   if (s->device >= 0) (void)hipSetDevice(s->device);
   DevBuf* bufs[] = {&s->d_nodes, &s->d_tris, &s->d_tri_face, &s->d_face_nm, &s->d_spheres, &s->d_sph_mat, &s->d_mats,
                     &s->d_lights, &s->d_slights, &s->d_leafboxes, &s->d_leaf_faces, &s->d_face_pos, &s->w_gi_rays,
-                    &s->w_gi_hits, &s->w_rays[0], &s->w_rays[1], &s->w_hits[0], &s->w_hits[1], &s->w_parents,
+                    &s->w_gi_hits, &s->w_cursors, &s->w_stack_ovf, &s->w_rays[0], &s->w_rays[1], &s->w_hits[0], &s->w_hits[1], &s->w_parents,
                     &s->w_shadow_rays, &s->w_shadow_hits, &s->w_counters, &s->w_io[0], &s->w_io[1], &s->w_io[2],
                     &s->w_io[3], &s->w_io[4], &s->w_io[5]};
   for (DevBuf* b : bufs) b->release();
@@ -378,7 +383,7 @@ extern "C" int rtx_scene_build(rtx_scene* s) {
   in.ntris = ntris; in.nverts = nverts; in.nnodes = (uint32_t)s->bvh.nodes.size(); in.nleaves = s->bvh.nleaves;
   in.max_depth = s->bvh.max_depth; in.nwild = s->nwild;
   in.build_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
-  if (s->bvh.max_depth + 2 > (uint32_t)kStackDepth) return fail(RTX_ELIMIT, "BVH depth %u exceeds the traversal stack", s->bvh.max_depth);
+  if (s->bvh.max_depth > (uint32_t)kStackDepth) return fail(RTX_ELIMIT, "BVH depth %u exceeds the traversal stack", s->bvh.max_depth);
   s->built = true;
   return RTX_OK;
 }
@@ -396,6 +401,7 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   s->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (int rc = rtx_scene_build(s)) return rc;
+  if (int rc = s->w_stack_ovf.ensure((size_t)trace_grid(s) * kBlock * (kStackDepth - kLdsStack) * 4)) return rc;
   const uint32_t ntris = (uint32_t)s->tri_mat.size();
   const std::vector<float4>& tri_leaf = s->h_tri_leaf;
   const std::vector<int32_t>& tri_face = s->h_tri_face;
@@ -499,6 +505,8 @@ static void span_end(rtx_scene* s, bool trace) {
   (void)hipEventRecord((trace ? s->trace_spans : s->all_spans).back().second, s->stream);
 }
 static void stats_begin(rtx_scene* s) {
+  s->cursors_used = 0;
+  if (s->w_cursors.ensure(64 * 4) == 0) (void)hipMemsetAsync(s->w_cursors.p, 0, 64 * 4, s->stream);
   s->events.reset(); s->trace_spans.clear(); s->all_spans.clear(); s->camera_span = (size_t)-1;
   std::memset(&s->stats, 0, sizeof s->stats);
   span_begin(s, false);
@@ -528,6 +536,33 @@ static int check_ready(rtx_scene* s) {
   return RTX_OK;
 }
 
+// Traversal launches: persistent waves (grid = what is resident), one work cursor per launch,
+// and the global overflow columns of the per-lane stacks.
+static int next_cursor(rtx_scene* s, uint32_t** out) {
+  if (s->cursors_used >= 64) return fail(RTX_ELIMIT, "too many traversal launches in one call");
+  *out = s->w_cursors.as<uint32_t>() + s->cursors_used++;
+  return RTX_OK;
+}
+// rays per group of the static round-robin (one wave-load)
+static uint32_t grab_size(uint64_t /*rays*/, uint32_t /*grid*/) { return 64; }
+static int launch_trace_camera(rtx_scene* s, const DevCamera& C, uint32_t tiles, uint2* hits) {
+  uint32_t* cur;
+  if (int rc = next_cursor(s, &cur)) return rc;
+  const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(tiles, 1), (uint32_t)trace_grid(s));
+  hipLaunchKernelGGL(k_trace_camera, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, C, tiles, grab_size((uint64_t)tiles * kBlock, grid),
+                     cur, s->w_stack_ovf.as<uint32_t>(), hits);
+  return RTX_OK;
+}
+static int launch_trace_queue(rtx_scene* s, const float4* rays, const uint32_t* count, uint32_t stride, uint64_t bound, uint2* hits) {
+  uint32_t* cur;
+  if (int rc = next_cursor(s, &cur)) return rc;
+  const uint64_t blocks = (bound * stride + kBlock - 1) / kBlock;
+  const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, (uint64_t)trace_grid(s)));
+  hipLaunchKernelGGL(k_trace_queue, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride,
+                     grab_size(bound * stride, grid), cur, s->w_stack_ovf.as<uint32_t>(), hits);
+  return RTX_OK;
+}
+
 // Traces `n` caller rays held on the device (xyz arrays) into w_hits[0]; w_rays[0] keeps the records.
 static int trace_rays_dev(rtx_scene* s, const float* d_o, const float* d_d, uint32_t n) {
   if (int rc = s->w_rays[0].ensure((size_t)n * 32)) return rc;
@@ -536,8 +571,7 @@ static int trace_rays_dev(rtx_scene* s, const float* d_o, const float* d_d, uint
   HIP_TRY(hipMemcpyAsync(s->w_counters.p, &n, 4, hipMemcpyHostToDevice, s->stream));
   hipLaunchKernelGGL(k_make_rays, dim3((n + 255) / 256), dim3(256), 0, s->stream, d_o, d_d, n, s->w_rays[0].as<float4>());
   span_begin(s, true);
-  hipLaunchKernelGGL(k_trace_queue, dim3(grid_for(s, n)), dim3(kBlock), 0, s->stream, s->dev, s->w_rays[0].as<float4>(),
-                     s->w_counters.as<uint32_t>(), 1u, s->w_hits[0].as<uint2>());
+  if (int rc = launch_trace_queue(s, s->w_rays[0].as<float4>(), s->w_counters.as<uint32_t>(), 1u, n, s->w_hits[0].as<uint2>())) return rc;
   span_end(s, true);
   return RTX_OK;
 }
@@ -604,8 +638,7 @@ extern "C" int rtx_trace_visible(rtx_scene* s, const float* light, const float* 
   hipLaunchKernelGGL(k_make_shadow_rays, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->w_io[0].as<float>(),
                      s->w_io[1].as<float>(), n, s->w_rays[0].as<float4>());
   span_begin(s, true);
-  hipLaunchKernelGGL(k_trace_queue, dim3(grid_for(s, n)), dim3(kBlock), 0, s->stream, s->dev, s->w_rays[0].as<float4>(),
-                     s->w_counters.as<uint32_t>(), 1u, s->w_hits[0].as<uint2>());
+  if (int rc = launch_trace_queue(s, s->w_rays[0].as<float4>(), s->w_counters.as<uint32_t>(), 1u, n, s->w_hits[0].as<uint2>())) return rc;
   span_end(s, true);
   hipLaunchKernelGGL(k_visible, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->dev, s->w_io[0].as<float>(),
                      s->w_rays[0].as<float4>(), s->w_hits[0].as<uint2>(), n, s->w_io[2].as<unsigned char>(), s->w_io[3].as<int>());
@@ -737,11 +770,9 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
   span_begin(s, true);
   if (pr.camera) {
     s->camera_span = s->trace_spans.size() - 1;
-    hipLaunchKernelGGL(k_trace_camera, dim3(std::min<uint32_t>(pr.tiles, (uint32_t)s->ncu * 64)), dim3(kBlock), 0, s->stream,
-                       s->dev, pr.C, pr.tiles, s->w_hits[0].as<uint2>());
+    if (int rc = launch_trace_camera(s, pr.C, pr.tiles, s->w_hits[0].as<uint2>())) return rc;
   } else {
-    hipLaunchKernelGGL(k_trace_queue, dim3(grid_for(s, pr.n0)), dim3(kBlock), 0, s->stream, s->dev, s->w_rays[0].as<float4>(),
-                       n0_dev, 1u, s->w_hits[0].as<uint2>());
+    if (int rc = launch_trace_queue(s, s->w_rays[0].as<float4>(), n0_dev, 1u, pr.n0, s->w_hits[0].as<uint2>())) return rc;
   }
   span_end(s, true);
 
@@ -769,8 +800,7 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
     if (!shade) break;
     if (opt->shadows && NLS) {
       span_begin(s, true);
-      hipLaunchKernelGGL(k_trace_queue, dim3(grid_for(s, bound * NLS)), dim3(kBlock), 0, s->stream, s->dev,
-                         s->w_shadow_rays.as<float4>(), cnt + 4 * g, NLS, s->w_shadow_hits.as<uint2>());
+      if (int rc = launch_trace_queue(s, s->w_shadow_rays.as<float4>(), cnt + 4 * g, NLS, bound, s->w_shadow_hits.as<uint2>())) return rc;
       span_end(s, true);
     }
     if (G) {
@@ -783,8 +813,7 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
     if (g < max_gen) {
       if (tree) bound *= 2;
       span_begin(s, true);
-      hipLaunchKernelGGL(k_trace_queue, dim3(grid_for(s, bound)), dim3(kBlock), 0, s->stream, s->dev, s->w_rays[nxt].as<float4>(),
-                         cnt + 4 * g + 1, 1u, s->w_hits[1].as<uint2>());
+      if (int rc = launch_trace_queue(s, s->w_rays[nxt].as<float4>(), cnt + 4 * g + 1, 1u, bound, s->w_hits[1].as<uint2>())) return rc;
       span_end(s, true);
     }
   }

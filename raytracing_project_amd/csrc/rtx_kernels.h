@@ -13,7 +13,10 @@
 namespace rtx {
 
 constexpr int kBlock = 256;          // 4 waves of 64
-constexpr int kStackDepth = 32;      // per-lane traversal stack entries, held in LDS
+constexpr int kStackDepth = 32;      // per-lane traversal stack entries in total (BVH depth <= 30)
+constexpr int kLdsStack = 12;        // the first entries live in LDS (12 KB per block -> 8 waves/SIMD);
+                                     // deeper ones (rare) spill to a per-thread global column
+constexpr uint32_t kMaxGrab = 256;   // most rays a wave takes from the work cursor per atomic
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr float kPrecision = 0.001f; // Intersect::Face::precision (src/Intersect.h:14)
 constexpr float kPruneSlack = 1.0001f;
@@ -140,10 +143,26 @@ __device__ __forceinline__ void test_triangle(const DevScene& S, uint32_t k, V3 
   }
 }
 
+// Per-lane traversal stack: entries [0, kLdsStack) in LDS (column of this thread, stride
+// kBlock, so lane <-> bank and no conflicts), entries beyond in global memory (column of this
+// thread, stride = threads in the grid, so a wave's accesses to one level coalesce).
+struct Stack {
+  uint32_t* lds;        // &lds_stack[threadIdx.x]
+  uint32_t* ovf;        // &overflow[global thread id]
+  uint32_t ovf_stride;
+  __device__ __forceinline__ void push(int sp, uint32_t v) const {
+    if (sp < kLdsStack) lds[sp * kBlock] = v;
+    else ovf[(size_t)(sp - kLdsStack) * ovf_stride] = v;
+  }
+  __device__ __forceinline__ uint32_t pop(int sp) const {
+    return sp < kLdsStack ? lds[sp * kBlock] : ovf[(size_t)(sp - kLdsStack) * ovf_stride];
+  }
+};
+
 // ---------------------------------------------------------------- closest hit
 // Flyscene::getIntersections (src/flyscene.cpp:517-585) for the ray Ray(o, .) whose stored
-// direction is d1.  `stk` points at this lane's column of the LDS stack (stride kBlock).
-__device__ __forceinline__ Hit closest_hit(const DevScene& S, V3 o, V3 d1, uint32_t* stk) {
+// direction is d1.
+__device__ __forceinline__ Hit closest_hit(const DevScene& S, V3 o, V3 d1, const Stack& stk) {
   Hit best; best.t = INFINITY; best.id = -1;
   // spheres first, strict < (src/flyscene.cpp:523-532)
   for (uint32_t i = 0; i < S.nspheres; ++i) {
@@ -193,7 +212,7 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& S, V3 o, V3 d1, uint3
       const uint32_t e1 = c1 ? (kLeafBit | (c1 << 28) | __float_as_uint(a1.w)) : __float_as_uint(a1.w);
       if (h0 && h1) {
         const bool first0 = tn0 <= tn1;
-        stk[sp * kBlock] = first0 ? e1 : e0;
+        stk.push(sp, first0 ? e1 : e0);
         ++sp;
         cur = first0 ? e0 : e1;
         continue;
@@ -206,7 +225,7 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& S, V3 o, V3 d1, uint3
     }
     if (sp == 0) break;
     --sp;
-    cur = stk[sp * kBlock];
+    cur = stk.pop(sp);
   }
   return best;
 }
@@ -261,28 +280,73 @@ __device__ __forceinline__ bool block_slot(const DevCamera& C, uint32_t block, u
 }
 
 // ---------------------------------------------------------------- kernels
-// One camera ray per lane over a pixel rectangle; writes {t, id} per pixel, row-major.
-__global__ __launch_bounds__(kBlock) void k_trace_camera(DevScene S, DevCamera C, uint32_t nblocks, uint2* hits) {
-  __shared__ uint32_t stack[kStackDepth * kBlock];
-  for (uint32_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-    int lx, ly; uint32_t slot;
-    if (!block_slot(C, blk, threadIdx.x, &slot, &lx, &ly)) continue;
-    V3 o, d1;
-    camera_ray(C, C.x0 + lx, C.y0 + ly, &o, &d1);
-    const Hit h = closest_hit(S, o, d1, stack + threadIdx.x);
-    hits[slot] = make_uint2(__float_as_uint(h.t), (uint32_t)h.id);
+// Persistent waves: the grid is sized to what is resident (8 blocks of 4 waves per CU) and
+// every wave takes `grab` consecutive ray indices at a time (struct Work), so expensive and
+// cheap regions of the image balance without any block-level synchronisation.
+__device__ __forceinline__ Stack make_stack(uint32_t* lds, uint32_t* ovf) {
+  Stack st;
+  st.lds = lds + threadIdx.x;
+  st.ovf = ovf + (size_t)blockIdx.x * kBlock + threadIdx.x;
+  st.ovf_stride = gridDim.x * kBlock;
+  return st;
+}
+// Work distribution.  RTX_WORK_STATIC (default): wave w of the grid takes the 64-ray groups
+// w, w + W, w + 2W, ... (W = waves in the grid) -- no atomics at all; every wave gets many
+// groups spread over the whole image, which averages the cost.  A single global cursor was
+// measured slower: at 64-192 rays per grab the ~40k atomics of a 4K frame serialise on one
+// L2 address (~88 dequeues/us), see DESIGN.md.
+struct Work {
+  uint32_t n, grab, next_base, step;
+  __device__ __forceinline__ bool next(uint32_t* base) {
+    *base = next_base;
+    next_base += step;
+    return *base < n;
+  }
+};
+__device__ __forceinline__ Work make_work(uint32_t* /*cursor*/, uint32_t n, uint32_t grab) {
+  Work w; w.n = n; w.grab = grab;
+  w.next_base = (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * grab;
+  w.step = gridDim.x * (kBlock / 64) * grab;
+  return w;
+}
+
+// Camera rays of a pixel rectangle.  Ray index j = (16x16 pixel block, thread): consecutive
+// indices walk 8x8 pixel sub-tiles, so the 64 rays of a wave stay coherent.  Writes {t, id}.
+__global__ __launch_bounds__(kBlock, 8) void k_trace_camera(DevScene S, DevCamera C, uint32_t nblocks, uint32_t grab, uint32_t* cursor,
+                                                          uint32_t* ovf, uint2* hits) {
+  __shared__ uint32_t lds_stack[kLdsStack * kBlock];
+  const Stack stk = make_stack(lds_stack, ovf);
+  const uint32_t n = nblocks * (uint32_t)kBlock;
+  Work work = make_work(cursor, n, grab);
+  uint32_t base;
+  while (work.next(&base)) {
+    const uint32_t end = base + grab < n ? base + grab : n;
+    for (uint32_t j = base + (threadIdx.x & 63); j < end; j += 64) {
+      int lx, ly; uint32_t slot;
+      if (!block_slot(C, j / kBlock, j % kBlock, &slot, &lx, &ly)) continue;
+      V3 o, d1;
+      camera_ray(C, C.x0 + lx, C.y0 + ly, &o, &d1);
+      const Hit h = closest_hit(S, o, d1, stk);
+      hits[slot] = make_uint2(__float_as_uint(h.t), (uint32_t)h.id);
+    }
   }
 }
 
-// Queued rays: rays[2i] = {o.xyz, aux}, rays[2i+1] = {d1.xyz, aux}; *count rays (device-side count).
-__global__ __launch_bounds__(kBlock) void k_trace_queue(DevScene S, const float4* rays, const uint32_t* count,
-                                                      uint32_t stride, uint2* hits) {
-  __shared__ uint32_t stack[kStackDepth * kBlock];
+// Queued rays: rays[2i] = {o.xyz, aux}, rays[2i+1] = {d1.xyz, aux}; *count * stride rays.
+__global__ __launch_bounds__(kBlock, 8) void k_trace_queue(DevScene S, const float4* rays, const uint32_t* count, uint32_t stride,
+                                                         uint32_t grab, uint32_t* cursor, uint32_t* ovf, uint2* hits) {
+  __shared__ uint32_t lds_stack[kLdsStack * kBlock];
+  const Stack stk = make_stack(lds_stack, ovf);
   const uint32_t n = *count * stride;
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const float4 ro = rays[2 * (size_t)i], rd = rays[2 * (size_t)i + 1];
-    const Hit h = closest_hit(S, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), stack + threadIdx.x);
-    hits[i] = make_uint2(__float_as_uint(h.t), (uint32_t)h.id);
+  Work work = make_work(cursor, n, grab);
+  uint32_t base;
+  while (work.next(&base)) {
+    const uint32_t end = base + grab < n ? base + grab : n;
+    for (uint32_t j = base + (threadIdx.x & 63); j < end; j += 64) {
+      const float4 ro = rays[2 * (size_t)j], rd = rays[2 * (size_t)j + 1];
+      const Hit h = closest_hit(S, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), stk);
+      hits[j] = make_uint2(__float_as_uint(h.t), (uint32_t)h.id);
+    }
   }
 }
 

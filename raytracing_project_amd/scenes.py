@@ -39,8 +39,9 @@ def soup(ntris, seed=0x5EED0001, h=0.02):
 
 
 def blob(nu=187, nv=188):
-    """Closed bumpy 'bunny-class' surface: a lat-long sphere (2*nu*nv - 2*nv ... triangles,
-    70,312 at the defaults) whose radius is modulated by a few low-frequency lobes."""
+    """Closed bumpy 'bunny-class' surface: a lat-long sphere (69,936 triangles at the defaults;
+    the Stanford bunny of BASELINE config 2 has 69,451) whose radius is modulated by a few
+    low-frequency lobes."""
     th = (np.arange(nu + 1, dtype=np.float64) / nu) * np.pi           # polar
     ph = (np.arange(nv, dtype=np.float64) / nv) * 2.0 * np.pi         # azimuth
     T, P = np.meshgrid(th, ph, indexing="ij")
@@ -56,8 +57,10 @@ def blob(nu=187, nv=188):
     b = (i * nv + (j + 1) % nv)
     c = ((i + 1) * nv + j)
     d = ((i + 1) * nv + (j + 1) % nv)
-    t1 = np.stack([a, c, b], -1).reshape(-1, 3)
-    t2 = np.stack([b, c, d], -1).reshape(-1, 3)
+    # the pole rings collapse to a point: drop their zero-area triangles (a == b at the first
+    # ring, c == d at the last), which leaves 2*nu*nv - 2*nv = 69,936 triangles at the defaults
+    t1 = np.stack([a, c, b], -1)[1:].reshape(-1, 3)
+    t2 = np.stack([b, c, d], -1)[:-1].reshape(-1, 3)
     idx = np.concatenate([t1, t2]).astype(np.uint32)
     return verts, idx
 
