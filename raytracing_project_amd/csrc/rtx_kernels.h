@@ -545,103 +545,143 @@ __device__ __forceinline__ V3 refract_dir(V3 n, V3 view, float n1, float n2) {
   return normalized(a - b);
 }
 
-// wave64 compaction: returns this lane's slot in a global list, or ~0u when !want
-__device__ __forceinline__ uint32_t wave_alloc(bool want, uint32_t* counter, uint32_t per_item) {
+// wave64 compaction inside a block: returns this lane's offset in the block's share of a
+// list (LDS running counter), or ~0u when !want.
+__device__ __forceinline__ uint32_t wave_alloc_lds(bool want, uint32_t* lds_counter) {
   const unsigned long long m = __ballot(want);
   if (m == 0) return ~0u;
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
   uint32_t base = 0;
   const int leader = __ffsll((long long)m) - 1;
-  if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m) * per_item);
+  if ((int)lane == leader) base = atomicAdd(lds_counter, (uint32_t)__popcll(m));
   base = __shfl(base, leader, 64);
-  return want ? base + rank * per_item : ~0u;
+  return want ? base + rank : ~0u;
+}
+
+// What a node spawns, from its hit record alone (shared by the counting and the writing pass).
+struct Spawn { bool valid, hit, refl, refr; float ht; int id; };
+__device__ __forceinline__ Spawn classify(const PipeArgs& A, uint32_t i) {
+  Spawn sp; sp.valid = true; sp.hit = sp.refl = sp.refr = false; sp.ht = INFINITY; sp.id = -1;
+  if (A.from_camera) { int x, y; sp.valid = slot_pixel(A.C, i, &x, &y); }
+  if (!sp.valid) return sp;
+  const uint2 h = A.hits[i];
+  sp.ht = __uint_as_float(h.x); sp.id = (int)h.y;
+  sp.hit = sp.id != -1;
+  if (sp.hit && A.bounce < A.max_bounces) {
+    sp.refl = A.reflection != 0; sp.refr = A.refraction != 0;
+    if (A.skip_zero_weight && (sp.refl || sp.refr)) {
+      const int m = sp.id >= 0 ? __float_as_int(A.S.face_nm[sp.id].w) : A.S.sph_mat[-2 - sp.id];
+      const float d = (m < 0 || m >= (int)A.S.nmats) ? 1.0f : A.S.mats[m].d;      // default Mtl: d = 1
+      if (1.0f - d == 0.0f) sp.refl = false;
+      if (d == 0.0f) sp.refr = false;
+    }
+  }
+  return sp;
 }
 
 // Flyscene::traceRay miss branch + the ray-spawning half of Shader/calculateColor
 // (src/flyscene.cpp:587-601, 686-702, 704-712, 723, 747-750).
+// Each block owns a contiguous range of nodes.  Pass 1 counts what the range spawns, one thread
+// reserves the block's share of the three output lists with ONE global atomic each, pass 2
+// writes the records using LDS counters.  (A global atomic per wave was the bottleneck of the
+// first version: ~90k atomics on three addresses per 4K frame, ~0.6 ms.)
 __global__ __launch_bounds__(kBlock) void k_shade(PipeArgs A) {
+  __shared__ uint32_t s_cnt[4], s_base[4], s_run[4];
   const uint32_t n = A.nrays ? *A.nrays : A.n0;
-  const uint32_t n_round = (n + 63u) & ~63u;    // whole waves enter the ballots
   const uint32_t NLS = light_samples(A.S);
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_round; i += gridDim.x * kBlock) {
-    const bool live = i < n;
-    RayRec r; r.valid = false; r.pixel = 0; r.thr = 0; r.inside = false; r.o = v3(0, 0, 0); r.d1 = v3(0, 0, 0);
-    float ht = INFINITY; int id = -1;
-    if (live) {
-      r = load_node(A, i);
-      const uint2 h = r.valid ? A.hits[i] : make_uint2(__float_as_uint(INFINITY), 0xFFFFFFFFu);
-      ht = __uint_as_float(h.x); id = (int)h.y;
-      if (A.first_gen && r.valid) {
-        if (A.out_t) A.out_t[i] = ht;
-        if (A.out_face) A.out_face[i] = id >= 0 ? id : -1;
-      }
+  const uint32_t per = (((n + gridDim.x - 1) / gridDim.x) + kBlock - 1) / kBlock * kBlock;
+  const uint32_t beg = blockIdx.x * per < n ? blockIdx.x * per : n;
+  const uint32_t end = beg + per < n ? beg + per : n;
+  if (threadIdx.x < 4) { s_cnt[threadIdx.x] = 0; s_run[threadIdx.x] = 0; s_base[threadIdx.x] = 0; }
+  __syncthreads();
+  if (A.rgb) {
+    uint32_t c_par = 0, c_next = 0, c_refr = 0;
+    for (uint32_t i = beg + threadIdx.x; i < end; i += kBlock) {
+      const Spawn sp = classify(A, i);
+      c_par += sp.hit; c_next += (uint32_t)sp.refl + (uint32_t)sp.refr; c_refr += sp.refr;
     }
-    const bool is_hit = live && (id != -1);
+    for (int off = 32; off > 0; off >>= 1) {
+      c_par += __shfl_down(c_par, off, 64); c_next += __shfl_down(c_next, off, 64); c_refr += __shfl_down(c_refr, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cnt[0], c_par); atomicAdd(&s_cnt[1], c_next); atomicAdd(&s_cnt[2], c_refr); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (s_cnt[0]) s_base[0] = atomicAdd(&A.counters[0], s_cnt[0]);
+      if (s_cnt[1]) s_base[1] = atomicAdd(&A.counters[1], s_cnt[1]);
+      if (s_cnt[2]) atomicAdd(&A.counters[2], s_cnt[2]);        // refraction tally for the statistics
+    }
+    __syncthreads();
+  }
+  for (uint32_t i0 = beg; i0 < end; i0 += kBlock) {
+    const uint32_t i = i0 + threadIdx.x;
+    const bool live = i < end;
+    Spawn sp; sp.valid = false; sp.hit = sp.refl = sp.refr = false; sp.ht = INFINITY; sp.id = -1;
+    if (live) sp = classify(A, i);
+    if (live && sp.valid && A.first_gen) {
+      if (A.out_t) A.out_t[i] = sp.ht;
+      if (A.out_face) A.out_face[i] = sp.id >= 0 ? sp.id : -1;
+    }
     if (!A.rgb) continue;   // hits only
-    if (live && r.valid && A.first_gen) {
+    RayRec r; r.valid = false; r.pixel = 0; r.thr = 0; r.inside = false; r.o = v3(0, 0, 0); r.d1 = v3(0, 0, 0);
+    if (live && sp.valid && (sp.hit || A.first_gen)) r = load_node(A, i);
+    if (live && sp.valid && A.first_gen) {
       // traceRay's miss colour at bounce 0 (src/flyscene.cpp:596-600); hit pixels start at 0 and
       // receive their nodes' colours from k_resolve
       float* px = A.rgb + 3 * (size_t)r.pixel;
-      const bool sky = !is_hit && A.bounce == 0;
+      const bool sky = !sp.hit && A.bounce == 0;
       px[0] = sky ? (float)0.69019607843 : 0.0f; px[1] = sky ? 1.0f : 0.0f; px[2] = sky ? 1.0f : 0.0f;
     }
-    const uint32_t slot = wave_alloc(is_hit, &A.counters[0], 1);
-    Surface sf; sf.P = v3(0, 0, 0); sf.N = v3(0, 0, 0); sf.mat = -1;
-    float wr = 0.0f, wt = 0.0f, ni = 0.0f;
-    if (is_hit) {
-      sf = surface_of(A.S, r.o, r.d1, ht, id);
-      A.parents[slot] = i;
-      if (A.shadows) {
-        for (uint32_t ls = 0; ls < NLS; ++ls) {
-          bool fifth;
-          const V3 L = light_sample(A, sf.P, ls, &fifth);
-          // canSeeLight: Ray(position, toLight.normalized()) normalises twice (src/flyscene.cpp:749-750)
-          const V3 d1s = normalized(normalized(L - sf.P));
-          const size_t k = (size_t)slot * NLS + ls;
-          A.shadow_rays[2 * k] = make_float4(sf.P.x, sf.P.y, sf.P.z, 0.0f);
-          A.shadow_rays[2 * k + 1] = make_float4(d1s.x, d1s.y, d1s.z, 0.0f);
-        }
+    const uint32_t off_par = wave_alloc_lds(sp.hit, &s_run[0]);
+    const uint32_t off_r = wave_alloc_lds(sp.refl, &s_run[1]);
+    const uint32_t off_t = wave_alloc_lds(sp.refr, &s_run[1]);
+    if (!sp.hit) continue;
+    const uint32_t slot = s_base[0] + off_par;
+    const Surface sf = surface_of(A.S, r.o, r.d1, sp.ht, sp.id);
+    A.parents[slot] = i;
+    if (A.shadows) {
+      for (uint32_t ls = 0; ls < NLS; ++ls) {
+        bool fifth;
+        const V3 L = light_sample(A, sf.P, ls, &fifth);
+        // canSeeLight: Ray(position, toLight.normalized()) normalises twice (src/flyscene.cpp:749-750)
+        const V3 d1s = normalized(normalized(L - sf.P));
+        const size_t k = (size_t)slot * NLS + ls;
+        A.shadow_rays[2 * k] = make_float4(sf.P.x, sf.P.y, sf.P.z, 0.0f);
+        A.shadow_rays[2 * k + 1] = make_float4(d1s.x, d1s.y, d1s.z, 0.0f);
       }
-      if (A.gi_rays > 0) {
-        // Ray::resendRay (src/Ray.h:43-57): the reflected direction rotated about the normal
-        float m[9];
-        angle_axis_matrix(A.gi_sin, A.gi_cos, sf.N, m);
-        V3 dir = normalized(reflect_dir(r.d1, sf.N));
-        for (int k = 0; k < A.gi_rays; ++k) {
-          dir = mat3_mul(m, dir);
-          const V3 dn = normalized(dir);
-          const size_t q = (size_t)slot * (uint32_t)A.gi_rays + (uint32_t)k;
-          A.gi_q[2 * q] = make_float4(sf.P.x, sf.P.y, sf.P.z, 0.0f);
-          A.gi_q[2 * q + 1] = make_float4(dn.x, dn.y, dn.z, 0.0f);
-        }
+    }
+    if (A.gi_rays > 0) {
+      // Ray::resendRay (src/Ray.h:43-57): the reflected direction rotated about the normal
+      float m[9];
+      angle_axis_matrix(A.gi_sin, A.gi_cos, sf.N, m);
+      V3 dir = normalized(reflect_dir(r.d1, sf.N));
+      for (int k = 0; k < A.gi_rays; ++k) {
+        dir = mat3_mul(m, dir);
+        const V3 dn = normalized(dir);
+        const size_t q = (size_t)slot * (uint32_t)A.gi_rays + (uint32_t)k;
+        A.gi_q[2 * q] = make_float4(sf.P.x, sf.P.y, sf.P.z, 0.0f);
+        A.gi_q[2 * q + 1] = make_float4(dn.x, dn.y, dn.z, 0.0f);
       }
+    }
+    if (sp.refl || sp.refr) {
       const DevMat mat = material_of(A.S, sf.mat);
-      wr = 1.0f - mat.d; wt = mat.d; ni = mat.ni;
-    }
-    const bool deeper = is_hit && (A.bounce < A.max_bounces);
-    const bool spawn_r = deeper && A.reflection && !(A.skip_zero_weight && wr == 0.0f);
-    const bool spawn_t = deeper && A.refraction && !(A.skip_zero_weight && wt == 0.0f);
-    // every light's calculateColor adds (1-d)*reflected + d*refracted once (src/flyscene.cpp:611-626,744)
-    const float nl_tot = (float)(A.S.nlights + A.S.nsl);
-    const uint32_t rs = wave_alloc(spawn_r, &A.counters[1], 1);
-    if (spawn_r) {
-      const V3 nd = normalized(reflect_dir(r.d1, sf.N));            // Ray::reflectRay (src/Ray.h:32-35)
-      const uint32_t pw = r.pixel | (r.inside ? 0x80000000u : 0u);
-      A.next_rays[2 * (size_t)rs] = make_float4(sf.P.x, sf.P.y, sf.P.z, __uint_as_float(pw));
-      A.next_rays[2 * (size_t)rs + 1] = make_float4(nd.x, nd.y, nd.z, r.thr * (wr * nl_tot));
-    }
-    const uint32_t ts = wave_alloc(spawn_t, &A.counters[1], 1);
-    {
-      const unsigned long long mt = __ballot(spawn_t);       // refraction tally for the statistics
-      if (mt && (int)(threadIdx.x & 63) == __ffsll((long long)mt) - 1) atomicAdd(&A.counters[2], (uint32_t)__popcll(mt));
-    }
-    if (spawn_t) {
-      const V3 eye = normalized(r.o - sf.P);
-      const V3 nd = r.inside ? refract_dir(-sf.N, -eye, ni, 1.0f) : refract_dir(sf.N, -eye, 1.0f, ni);   // :691-701
-      const uint32_t pw = r.pixel | (r.inside ? 0u : 0x80000000u);
-      A.next_rays[2 * (size_t)ts] = make_float4(sf.P.x, sf.P.y, sf.P.z, __uint_as_float(pw));
-      A.next_rays[2 * (size_t)ts + 1] = make_float4(nd.x, nd.y, nd.z, r.thr * (wt * nl_tot));
+      // every light's calculateColor adds (1-d)*reflected + d*refracted once (src/flyscene.cpp:611-626,744)
+      const float nl_tot = (float)(A.S.nlights + A.S.nsl);
+      if (sp.refl) {
+        const V3 nd = normalized(reflect_dir(r.d1, sf.N));            // Ray::reflectRay (src/Ray.h:32-35)
+        const uint32_t pw = r.pixel | (r.inside ? 0x80000000u : 0u);
+        const size_t q = s_base[1] + off_r;
+        A.next_rays[2 * q] = make_float4(sf.P.x, sf.P.y, sf.P.z, __uint_as_float(pw));
+        A.next_rays[2 * q + 1] = make_float4(nd.x, nd.y, nd.z, r.thr * ((1.0f - mat.d) * nl_tot));
+      }
+      if (sp.refr) {
+        const V3 eye = normalized(r.o - sf.P);
+        const V3 nd = r.inside ? refract_dir(-sf.N, -eye, mat.ni, 1.0f) : refract_dir(sf.N, -eye, 1.0f, mat.ni);   // :691-701
+        const uint32_t pw = r.pixel | (r.inside ? 0u : 0x80000000u);
+        const size_t q = s_base[1] + off_t;
+        A.next_rays[2 * q] = make_float4(sf.P.x, sf.P.y, sf.P.z, __uint_as_float(pw));
+        A.next_rays[2 * q + 1] = make_float4(nd.x, nd.y, nd.z, r.thr * (mat.d * nl_tot));
+      }
     }
   }
 }
@@ -717,7 +757,12 @@ __global__ __launch_bounds__(kBlock) void k_resolve(PipeArgs A) {
       if (visible) {
         const V3 ambient = cmul(ka, Iv);
         const V3 diffuse = md * cmul(v3(mat.kd[0], mat.kd[1], mat.kd[2]), Iv);
-        const float sp = (float)pow((double)mdot, 33.0);
+        // std::pow(float, 33) (src/flyscene.cpp:729): evaluated in double like libstdc++ does, by
+        // repeated squaring (x^32 * x) instead of the generic pow -- a few double ulps apart at
+        // most, far inside the 1e-4 RGB tolerance, and ~20x fewer instructions
+        const double xd = (double)mdot;
+        const double x2 = xd * xd, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8;
+        const float sp = (float)((x16 * x16) * xd);
         const V3 specular = cmul(Iv, v3(mat.ks[0], mat.ks[1], mat.ks[2])) * sp;
         c = ((ambient + diffuse) + specular) + gi;
       } else {
