@@ -77,6 +77,7 @@ typedef struct {
   uint64_t device_bytes;
   float build_ms;
   uint32_t nwild;     /* ill-conditioned triangles kept out of the BVH (tested by every ray) */
+  uint32_t nslots;    /* non-empty node slots; nnodes counts all 32-byte slots (4 per group) */
 } rtx_scene_info;
 
 const char* rtx_last_error(void);
@@ -128,7 +129,10 @@ int rtx_scene_build(rtx_scene*);
 int rtx_scene_commit(rtx_scene*, int device);
 int rtx_scene_get_info(const rtx_scene*, rtx_scene_info*);
 /* Host copy of the flattened acceleration structure (tests / roofline accounting).
- * nodes: nnodes x 8 words {lo.xyz, leftOrFirst, hi.xyz, count}; tri_face: ntris ids in leaf order,
+ * nodes: nnodes x 8 words {lo.xyz, ref, hi.xyz, count}, in groups of 4 siblings (128 bytes); group 0
+ * holds the root's children.  count > 0: leaf over triangles [ref, ref+count); count == 0: internal,
+ * ref = index of its child group; ref == 0xFFFFFFFF: unused slot.  max_depth counts group levels.
+ * tri_face: ntris ids in leaf order,
  * the last rtx_scene_info.nwild of them being the triangles outside the hierarchy. */
 int rtx_scene_get_bvh(const rtx_scene*, uint32_t* nodes8, uint32_t* tri_face);
 /* Host copy of the leaf-ordered 64-byte triangle records: ntris x 16 floats

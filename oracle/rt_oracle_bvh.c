@@ -95,29 +95,33 @@ static void* bvh_worker(void* arg) {
       for (int k = 0; k < 3; ++k) { iv[k] = 1.0f / d[k]; if (!(fabsf(iv[k]) <= 1e18f)) iv[k] = copysignf(1e18f, d[k]); }
       float oi[3] = {o[0] * iv[0], o[1] * iv[1], o[2] * iv[2]};
       for (uint32_t k = j->ntris - j->nwild; k < j->ntris; ++k) { ++tt; tri_test(j, k, o, d, &best_t, &best_id); }
-      const uint32_t* root = j->nodes;
-      uint32_t cur = root[7] ? (LEAF_BIT | (root[7] << 28) | root[3]) : root[3];
+      uint32_t cur = 0;     /* group 0 = children of the root */
       int sp = 0;
       if (j->nwild < j->ntris) for (;;) {
         if (!(cur & LEAF_BIT)) {
-          const uint32_t* n0 = j->nodes + 8 * (size_t)cur;
-          const uint32_t* n1 = n0 + 8;
-          nv += 2;
-          float lim = best_t * PRUNE_SLACK, tn0, tf0, tn1, tf1;
-          slab(n0, iv, oi, &tn0, &tf0);
-          slab(n1, iv, oi, &tn1, &tf1);
-          int h0 = (tn0 <= tf0) && (tf0 >= 0.0f) && (tn0 <= lim);
-          int h1 = (tn1 <= tf1) && (tf1 >= 0.0f) && (tn1 <= lim);
-          uint32_t e0 = n0[7] ? (LEAF_BIT | (n0[7] << 28) | n0[3]) : n0[3];
-          uint32_t e1 = n1[7] ? (LEAF_BIT | (n1[7] << 28) | n1[3]) : n1[3];
-          if (h0 && h1) {
-            int first0 = tn0 <= tn1;
-            stack[sp++] = first0 ? e1 : e0;
-            cur = first0 ? e0 : e1;
+          const uint32_t* q = j->nodes + 32 * (size_t)cur;      /* 4 sibling slots of 8 words */
+          float lim = best_t * PRUNE_SLACK, tn[4];
+          uint32_t en[4];
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t* nd = q + 8 * k;
+            float n_, f_;
+            slab(nd, iv, oi, &n_, &f_);
+            uint32_t ref = nd[3], c = nd[7];
+            if (ref != 0xFFFFFFFFu) nv += 1;
+            int h = (n_ <= f_) && (f_ >= 0.0f) && (n_ <= lim) && (ref != 0xFFFFFFFFu);
+            tn[k] = h ? n_ : INFINITY;
+            en[k] = c ? (LEAF_BIT | (c << 28) | ref) : ref;
+          }
+#define CX(a, b) do { if (tn[b] < tn[a]) { float tf_ = tn[a]; tn[a] = tn[b]; tn[b] = tf_; uint32_t te_ = en[a]; en[a] = en[b]; en[b] = te_; } } while (0)
+          CX(0, 1); CX(2, 3); CX(0, 2); CX(1, 3); CX(1, 2);
+#undef CX
+          if (tn[0] != INFINITY) {
+            if (tn[3] != INFINITY) stack[sp++] = en[3];
+            if (tn[2] != INFINITY) stack[sp++] = en[2];
+            if (tn[1] != INFINITY) stack[sp++] = en[1];
+            cur = en[0];
             continue;
           }
-          if (h0) { cur = e0; continue; }
-          if (h1) { cur = e1; continue; }
         } else {
           uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
           for (uint32_t k = first; k < first + cnt; ++k) { ++tt; tri_test(j, k, o, d, &best_t, &best_id); }

@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librtx.so")
+LIB_PATH = os.environ.get("RTX_LIB", os.path.join(HERE, "librtx.so"))   # RTX_LIB: A/B builds of the same library
 
 _f = C.POINTER(C.c_float)
 _i = C.POINTER(C.c_int32)
@@ -41,7 +41,7 @@ class SceneInfo(C.Structure):
     _fields_ = [("ntris", C.c_uint32), ("nverts", C.c_uint32), ("nnodes", C.c_uint32), ("nleaves", C.c_uint32),
                 ("max_depth", C.c_uint32), ("nspheres", C.c_uint32), ("nlights", C.c_uint32),
                 ("nmaterials", C.c_uint32), ("device_bytes", C.c_uint64), ("build_ms", C.c_float),
-                ("nwild", C.c_uint32)]
+                ("nwild", C.c_uint32), ("nslots", C.c_uint32)]
 
 
 # every symbol include/rtx.h declares

@@ -223,4 +223,60 @@ void build_bvh(const float* tri_lo, const float* tri_hi, uint32_t ntris, int thr
   }
 }
 
+
+namespace {
+uint32_t collapse_node(const std::vector<BvhNode>& bin, uint32_t b, std::vector<BvhNode>& q, uint32_t depth, BvhBuildResult* out) {
+  // candidates: the two children of b, each replaced by its own children when internal
+  uint32_t cand[4]; int nc = 0;
+  const uint32_t kids[2] = {bin[b].leftFirst, bin[b].leftFirst + 1};
+  for (int k = 0; k < 2; ++k) {
+    const BvhNode& c = bin[kids[k]];
+    if (c.count == 0) { cand[nc++] = c.leftFirst; cand[nc++] = c.leftFirst + 1; }
+    else cand[nc++] = kids[k];
+  }
+  const uint32_t g = (uint32_t)(q.size() / 4);
+  q.resize(q.size() + 4);
+  out->quad_depth = std::max(out->quad_depth, depth);
+  for (int k = 0; k < 4; ++k) {
+    BvhNode s;
+    if (k < nc) {
+      s = bin[cand[k]];
+      ++out->quad_slots;
+    } else {
+      for (int a = 0; a < 3; ++a) { s.lo[a] = FLT_MAX; s.hi[a] = -FLT_MAX; }
+      s.leftFirst = kEmptySlot; s.count = 0;
+    }
+    q[4 * (size_t)g + k] = s;
+  }
+  for (int k = 0; k < nc; ++k) {
+    if (bin[cand[k]].count == 0) {
+      const uint32_t child = collapse_node(bin, cand[k], q, depth + 1, out);
+      q[4 * (size_t)g + k].leftFirst = child;
+    }
+  }
+  return g;
+}
+}  // namespace
+
+void collapse_to_quads(BvhBuildResult* out) {
+  out->quads.clear(); out->quad_depth = 0; out->quad_slots = 0;
+  const std::vector<BvhNode>& bin = out->nodes;
+  const BvhNode& root = bin[0];
+  if (root.count == 0 && bin.size() >= 3) {        // internal root
+    out->quads.reserve(bin.size() * 2);
+    collapse_node(bin, 0, out->quads, 1, out);
+    return;
+  }
+  // leaf root (<= 4 triangles) or empty mesh: one group holding the root itself / nothing
+  out->quads.resize(4);
+  for (int k = 0; k < 4; ++k) {
+    BvhNode s;
+    for (int a = 0; a < 3; ++a) { s.lo[a] = FLT_MAX; s.hi[a] = -FLT_MAX; }
+    s.leftFirst = kEmptySlot; s.count = 0;
+    out->quads[k] = s;
+  }
+  out->quad_depth = 1;
+  if (root.count > 0) { out->quads[0] = root; out->quad_slots = 1; }
+}
+
 }  // namespace rtx

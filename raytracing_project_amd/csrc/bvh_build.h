@@ -17,18 +17,32 @@ struct BvhNode {
 };
 static_assert(sizeof(BvhNode) == 32, "node must be 32 bytes");
 
+// Marks an unused slot of a 4-slot group (see collapse_to_quads).
+constexpr uint32_t kEmptySlot = 0xFFFFFFFFu;
+
 struct BvhBuildResult {
-  std::vector<BvhNode> nodes;      // nodes[0] = root
+  std::vector<BvhNode> quads;      // traversal layout: groups of 4 sibling slots, group 0 = children of the root
+  uint32_t quad_depth = 0;         // levels of groups (root group = 1)
+  uint32_t quad_slots = 0;         // non-empty slots
+  std::vector<BvhNode> nodes;      // binary tree the groups are collapsed from; nodes[0] = root
   std::vector<uint32_t> order;     // leaf order -> input triangle id
   uint32_t nleaves = 0;
   uint32_t max_depth = 0;          // root = depth 0
 };
 
 constexpr int kMaxLeafTris = 4;    // fits the 3-bit count of the traversal stack entry (<= 7)
-constexpr int kMaxDepth = 30;      // traversal stack has 32 entries per lane
+constexpr int kMaxDepth = 30;      // binary depth; the collapsed tree has <= 15 levels of groups
 
 // tri_lo/tri_hi: per-triangle (already padded) bounds, 3 floats each.
 // Binned-SAH top-down build; deterministic for a given input regardless of thread count.
 void build_bvh(const float* tri_lo, const float* tri_hi, uint32_t ntris, int threads, BvhBuildResult* out);
+
+// Collapses the binary tree into the layout the kernels walk: every internal node's two
+// children are replaced by their own children where those are internal, giving groups of up
+// to 4 sibling 32-byte nodes stored contiguously (128 bytes = one cache line per traversal
+// step instead of two dependent 64-byte fetches).  A slot is {lo, ref, hi, count}:
+// count > 0 leaf over triangles [ref, ref+count); count == 0 internal, ref = index of its
+// child group; ref == kEmptySlot unused.  Fills out->quads / quad_depth / quad_slots.
+void collapse_to_quads(BvhBuildResult* out);
 
 }  // namespace rtx

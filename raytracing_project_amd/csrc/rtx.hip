@@ -355,6 +355,7 @@ extern "C" int rtx_scene_build(rtx_scene* s) {
   int threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
   const uint32_t nreg = (uint32_t)regular.size();
   build_bvh(lo.data(), hi.data(), nreg, threads, &s->bvh);
+  collapse_to_quads(&s->bvh);
   for (uint32_t k = 0; k < nreg; ++k) s->bvh.order[k] = regular[s->bvh.order[k]];
   s->bvh.order.insert(s->bvh.order.end(), wild.begin(), wild.end());
   s->nwild = (uint32_t)wild.size();
@@ -380,10 +381,10 @@ extern "C" int rtx_scene_build(rtx_scene* s) {
   auto t1 = std::chrono::steady_clock::now();
   rtx_scene_info& in = s->info;
   std::memset(&in, 0, sizeof in);
-  in.ntris = ntris; in.nverts = nverts; in.nnodes = (uint32_t)s->bvh.nodes.size(); in.nleaves = s->bvh.nleaves;
-  in.max_depth = s->bvh.max_depth; in.nwild = s->nwild;
+  in.ntris = ntris; in.nverts = nverts; in.nnodes = (uint32_t)s->bvh.quads.size(); in.nleaves = s->bvh.nleaves;
+  in.max_depth = s->bvh.quad_depth; in.nwild = s->nwild; in.nslots = s->bvh.quad_slots;
   in.build_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
-  if (s->bvh.max_depth > (uint32_t)kStackDepth) return fail(RTX_ELIMIT, "BVH depth %u exceeds the traversal stack", s->bvh.max_depth);
+  if (3 * s->bvh.quad_depth > (uint32_t)kStackDepth) return fail(RTX_ELIMIT, "BVH depth %u exceeds the traversal stack", s->bvh.quad_depth);
   s->built = true;
   return RTX_OK;
 }
@@ -420,7 +421,7 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   std::vector<float4> ds(std::max<size_t>(s->spheres.size() / 4, 1));
   for (size_t i = 0; i < s->spheres.size() / 4; ++i) ds[i] = make_float4(s->spheres[4 * i], s->spheres[4 * i + 1], s->spheres[4 * i + 2], s->spheres[4 * i + 3]);
   std::vector<int32_t> dsm = s->sph_mat; if (dsm.empty()) dsm.push_back(-1);
-  if (int rc = upload(s->d_nodes, s->bvh.nodes, s->stream)) return rc;
+  if (int rc = upload(s->d_nodes, s->bvh.quads, s->stream)) return rc;
   if (int rc = upload(s->d_tris, tri_leaf, s->stream)) return rc;
   if (int rc = upload(s->d_tri_face, tri_face, s->stream)) return rc;
   if (int rc = upload(s->d_face_nm, face_nm, s->stream)) return rc;
@@ -457,8 +458,7 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   d.ntris = ntris; d.nwild = s->nwild; d.nspheres = (uint32_t)(s->spheres.size() / 4); d.nlights = (uint32_t)(s->lights.size() / 3);
   d.nmats = (uint32_t)s->mats.size();
   for (int k = 0; k < 3; ++k) { d.root_lo[k] = s->root_lo[k]; d.root_hi[k] = s->root_hi[k]; }
-  const BvhNode& root = s->bvh.nodes[0];
-  d.root_entry = root.count ? (kLeafBit | (root.count << 28) | root.leftFirst) : root.leftFirst;
+  d.root_entry = 0;     // group 0 holds the children of the root
   rtx_scene_info& in = s->info;
   in.nspheres = d.nspheres; in.nlights = d.nlights; in.nmaterials = d.nmats;
   in.device_bytes = s->d_nodes.cap + s->d_tris.cap + s->d_tri_face.cap + s->d_face_nm.cap + s->d_spheres.cap +
@@ -485,7 +485,7 @@ extern "C" int rtx_scene_get_tris(const rtx_scene* s, float* tri16) {
 extern "C" int rtx_scene_get_bvh(const rtx_scene* s, uint32_t* nodes8, uint32_t* tri_face) {
   if (!s) return fail(RTX_EINVAL, "null scene");
   if (!s->built) return fail(RTX_ESTATE, "scene not built (rtx_scene_build / rtx_scene_commit)");
-  if (nodes8) std::memcpy(nodes8, s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(BvhNode));
+  if (nodes8) std::memcpy(nodes8, s->bvh.quads.data(), s->bvh.quads.size() * sizeof(BvhNode));
   if (tri_face) std::memcpy(tri_face, s->bvh.order.data(), s->bvh.order.size() * 4);
   return RTX_OK;
 }

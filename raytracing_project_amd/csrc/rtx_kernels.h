@@ -13,11 +13,12 @@
 namespace rtx {
 
 constexpr int kBlock = 256;          // 4 waves of 64
-constexpr int kStackDepth = 32;      // per-lane traversal stack entries in total (BVH depth <= 30)
+constexpr int kStackDepth = 48;      // per-lane traversal stack entries in total (<= 3 per level of 4-node groups, <= 15 levels)
 constexpr int kLdsStack = 12;        // the first entries live in LDS (12 KB per block -> 8 waves/SIMD);
                                      // deeper ones (rare) spill to a per-thread global column
 constexpr uint32_t kMaxGrab = 256;   // most rays a wave takes from the work cursor per atomic
 constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kEmptyRef = 0xFFFFFFFFu;   // unused slot of a 4-node group
 constexpr float kPrecision = 0.001f; // Intersect::Face::precision (src/Intersect.h:14)
 constexpr float kPruneSlack = 1.0001f;
 
@@ -25,7 +26,7 @@ struct DevMat { float ka[3], kd[3], ks[3]; float ns, ni, d; int illum; int pad[3
 static_assert(sizeof(DevMat) == 64, "material record is 64 bytes");
 
 struct DevScene {
-  const float4* nodes;     // 2 x float4 per node: {lo.xyz, leftFirst}, {hi.xyz, count}
+  const float4* nodes;     // 2 x float4 per 32-byte node {lo.xyz, ref}, {hi.xyz, count}; groups of 4 siblings (128 B)
   const float4* tris;      // 4 x float4 per leaf-ordered triangle: {v0,D} {u,uu} {v,uv} {n,vv}
   const int* tri_face;     // leaf order -> mesh face id
   const float4* face_nm;   // per mesh face: {query normal xyz, material id bits}
@@ -187,38 +188,35 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& S, V3 o, V3 d1, const
   int sp = 0;
   for (;;) {
     if (!(cur & kLeafBit)) {
-      const float4 a0 = S.nodes[2 * cur], b0 = S.nodes[2 * cur + 1];
-      const float4 a1 = S.nodes[2 * cur + 2], b1 = S.nodes[2 * cur + 3];
+      // one 128-byte group of 4 sibling nodes per step
+      const float4* q = S.nodes + 8 * (size_t)cur;
       const float lim = best.t * kPruneSlack;
-      float tn0, tf0, tn1, tf1;
-      {
-        float x0 = __builtin_fmaf(a0.x, ivx, -oix), x1 = __builtin_fmaf(b0.x, ivx, -oix);
-        float y0 = __builtin_fmaf(a0.y, ivy, -oiy), y1 = __builtin_fmaf(b0.y, ivy, -oiy);
-        float z0 = __builtin_fmaf(a0.z, ivz, -oiz), z1 = __builtin_fmaf(b0.z, ivz, -oiz);
-        tn0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-        tf0 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+      float tn[4]; uint32_t en[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float4 a = q[2 * k], b = q[2 * k + 1];
+        const float x0 = __builtin_fmaf(a.x, ivx, -oix), x1 = __builtin_fmaf(b.x, ivx, -oix);
+        const float y0 = __builtin_fmaf(a.y, ivy, -oiy), y1 = __builtin_fmaf(b.y, ivy, -oiy);
+        const float z0 = __builtin_fmaf(a.z, ivz, -oiz), z1 = __builtin_fmaf(b.z, ivz, -oiz);
+        const float n_ = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+        const float f_ = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        const uint32_t ref = __float_as_uint(a.w), c = __float_as_uint(b.w);
+        const bool h = (n_ <= f_) && (f_ >= 0.0f) && (n_ <= lim) && (ref != kEmptyRef);
+        tn[k] = h ? n_ : INFINITY;
+        en[k] = c ? (kLeafBit | (c << 28) | ref) : ref;
       }
-      {
-        float x0 = __builtin_fmaf(a1.x, ivx, -oix), x1 = __builtin_fmaf(b1.x, ivx, -oix);
-        float y0 = __builtin_fmaf(a1.y, ivy, -oiy), y1 = __builtin_fmaf(b1.y, ivy, -oiy);
-        float z0 = __builtin_fmaf(a1.z, ivz, -oiz), z1 = __builtin_fmaf(b1.z, ivz, -oiz);
-        tn1 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-        tf1 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-      }
-      const bool h0 = (tn0 <= tf0) && (tf0 >= 0.0f) && (tn0 <= lim);
-      const bool h1 = (tn1 <= tf1) && (tf1 >= 0.0f) && (tn1 <= lim);
-      const uint32_t c0 = __float_as_uint(b0.w), c1 = __float_as_uint(b1.w);
-      const uint32_t e0 = c0 ? (kLeafBit | (c0 << 28) | __float_as_uint(a0.w)) : __float_as_uint(a0.w);
-      const uint32_t e1 = c1 ? (kLeafBit | (c1 << 28) | __float_as_uint(a1.w)) : __float_as_uint(a1.w);
-      if (h0 && h1) {
-        const bool first0 = tn0 <= tn1;
-        stk.push(sp, first0 ? e1 : e0);
-        ++sp;
-        cur = first0 ? e0 : e1;
+      // sort the 4 candidates near-to-far (5 compare-exchanges); misses carry tn = +inf
+#define RTX_CX(i, j) { const bool sw = tn[j] < tn[i]; const float tt_ = sw ? tn[j] : tn[i]; tn[j] = sw ? tn[i] : tn[j]; tn[i] = tt_; \
+                       const uint32_t ee_ = sw ? en[j] : en[i]; en[j] = sw ? en[i] : en[j]; en[i] = ee_; }
+      RTX_CX(0, 1) RTX_CX(2, 3) RTX_CX(0, 2) RTX_CX(1, 3) RTX_CX(1, 2)
+#undef RTX_CX
+      if (tn[0] != INFINITY) {
+        if (tn[3] != INFINITY) { stk.push(sp, en[3]); ++sp; }
+        if (tn[2] != INFINITY) { stk.push(sp, en[2]); ++sp; }
+        if (tn[1] != INFINITY) { stk.push(sp, en[1]); ++sp; }
+        cur = en[0];
         continue;
       }
-      if (h0) { cur = e0; continue; }
-      if (h1) { cur = e1; continue; }
     } else {
       const uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
       for (uint32_t k = first; k < first + cnt; ++k) test_triangle(S, k, o, d, &best);
