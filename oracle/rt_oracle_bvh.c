@@ -33,6 +33,7 @@ typedef struct {
   const float* root_lo; const float* root_hi;
   const float* o; const float* d1; int n, tid, nthreads;
   float* t; int32_t* face; uint32_t* nodes_visited; uint32_t* tris_tested;
+  uint8_t* ev; uint32_t ev_stride; uint32_t* nev;   /* optional step log (wave-scheduling studies) */
 } bvh_job;
 
 /* reference root gate: Intersect::BoxObject::intersects (src/Intersect.cpp:67-145) */
@@ -89,7 +90,8 @@ static void* bvh_worker(void* arg) {
     float d[3];
     normalize3f(j->d1 + 3 * i, d);
     float best_t = INFINITY; int best_id = -1;
-    uint32_t nv = 0, tt = 0;
+    uint32_t nv = 0, tt = 0, ne = 0;
+    uint8_t* ev = j->ev ? j->ev + (size_t)i * j->ev_stride : NULL;
     if (j->ntris && gate(o, d, j->root_lo, j->root_hi) != INFINITY) {
       float iv[3];
       for (int k = 0; k < 3; ++k) { iv[k] = 1.0f / d[k]; if (!(fabsf(iv[k]) <= 1e18f)) iv[k] = copysignf(1e18f, d[k]); }
@@ -101,6 +103,8 @@ static void* bvh_worker(void* arg) {
         if (!(cur & LEAF_BIT)) {
           const uint32_t* q = j->nodes + 32 * (size_t)cur;      /* 4 sibling slots of 8 words */
           float lim = best_t * PRUNE_SLACK, tn[4];
+          if (ev && ne < j->ev_stride) ev[ne] = 0;
+          ++ne;
           uint32_t en[4];
           for (int k = 0; k < 4; ++k) {
             const uint32_t* nd = q + 8 * k;
@@ -108,7 +112,8 @@ static void* bvh_worker(void* arg) {
             slab(nd, iv, oi, &n_, &f_);
             uint32_t ref = nd[3], c = nd[7];
             if (ref != 0xFFFFFFFFu) nv += 1;
-            int h = (n_ <= f_) && (f_ >= 0.0f) && (n_ <= lim) && (ref != 0xFFFFFFFFu);
+            n_ = fmaxf(n_, 0.0f); f_ = fminf(f_, lim);      /* entry clamped to the ray start, exit to the limit */
+            int h = (n_ <= f_) && (ref != 0xFFFFFFFFu);
             tn[k] = h ? n_ : INFINITY;
             en[k] = c ? (LEAF_BIT | (c << 28) | ref) : ref;
           }
@@ -124,6 +129,8 @@ static void* bvh_worker(void* arg) {
           }
         } else {
           uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
+          if (ev && ne < j->ev_stride) ev[ne] = (uint8_t)cnt;
+          ++ne;
           for (uint32_t k = first; k < first + cnt; ++k) { ++tt; tri_test(j, k, o, d, &best_t, &best_id); }
         }
         if (sp == 0) break;
@@ -133,6 +140,7 @@ static void* bvh_worker(void* arg) {
     j->t[i] = best_t; j->face[i] = best_id;
     if (j->nodes_visited) j->nodes_visited[i] = nv;
     if (j->tris_tested) j->tris_tested[i] = tt;
+    if (j->nev) j->nev[i] = ne;
   }
   return NULL;
 }
@@ -150,10 +158,23 @@ void ora_bvh_trace(const uint32_t* nodes8, const float* tri16, const int32_t* tr
     j->nodes = nodes8; j->tris = tri16; j->tri_face = tri_face; j->ntris = ntris; j->nwild = nwild; j->root_lo = root_lo; j->root_hi = root_hi;
     j->o = o; j->d1 = d1; j->n = n; j->tid = i; j->nthreads = threads; j->t = t; j->face = face;
     j->nodes_visited = nodes_visited; j->tris_tested = tris_tested;
+    j->ev = NULL; j->ev_stride = 0; j->nev = NULL;
   }
   if (threads == 1) { bvh_worker(&jobs[0]); return; }
   for (int i = 0; i < threads; ++i) pthread_create(&th[i], NULL, bvh_worker, &jobs[i]);
   for (int i = 0; i < threads; ++i) pthread_join(th[i], NULL);
+}
+
+/* Step log of the same traversal: ev[i*stride + s] = 0 for a node-group step, k > 0 for a leaf
+ * step over k triangles; nev[i] = number of steps (may exceed stride: then the log is cut). */
+void ora_bvh_trace_events(const uint32_t* nodes8, const float* tri16, const int32_t* tri_face, uint32_t ntris, uint32_t nwild,
+                          const float* root_lo, const float* root_hi, const float* o, const float* d1, int n,
+                          float* t, int32_t* face, uint8_t* ev, uint32_t stride, uint32_t* nev) {
+  bvh_job j;
+  j.nodes = nodes8; j.tris = tri16; j.tri_face = tri_face; j.ntris = ntris; j.nwild = nwild; j.root_lo = root_lo; j.root_hi = root_hi;
+  j.o = o; j.d1 = d1; j.n = n; j.tid = 0; j.nthreads = 1; j.t = t; j.face = face; j.nodes_visited = NULL; j.tris_tested = NULL;
+  j.ev = ev; j.ev_stride = stride; j.nev = nev;
+  bvh_worker(&j);
 }
 
 /* Primary-ray directions of a camera over a pixel rectangle, as Ray objects hold them (d1). */

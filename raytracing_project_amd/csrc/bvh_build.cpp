@@ -279,4 +279,58 @@ void collapse_to_quads(BvhBuildResult* out) {
   if (root.count > 0) { out->quads[0] = root; out->quad_slots = 1; }
 }
 
+void pack_groups(const std::vector<BvhNode>& quads, std::vector<PackedGroup>* out) {
+  const size_t ng = quads.size() / 4;
+  out->assign(ng, PackedGroup{});
+  for (size_t g = 0; g < ng; ++g) {
+    const BvhNode* q = &quads[4 * g];
+    PackedGroup& P = (*out)[g];
+    float glo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, ghi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    bool any = false;
+    for (int k = 0; k < 4; ++k) {
+      if (q[k].leftFirst == kEmptySlot && q[k].count == 0) continue;
+      any = true;
+      for (int a = 0; a < 3; ++a) { glo[a] = std::min(glo[a], q[k].lo[a]); ghi[a] = std::max(ghi[a], q[k].hi[a]); }
+    }
+    uint32_t planes[6] = {0, 0, 0, 0, 0, 0};   // lox loy loz hix hiy hiz
+    P.exps = 0;
+    for (int a = 0; a < 3; ++a) {
+      if (!any) { glo[a] = 0.0f; ghi[a] = 0.0f; }
+      P.origin[a] = glo[a];
+      // smallest power-of-two step with origin + 255 * step >= ghi (in the kernel's fp32 arithmetic)
+      int e = 27;                                              // 2^-100: flat groups
+      const float ext = ghi[a] - glo[a];
+      if (ext > 0.0f) {
+        int ex; std::frexp((double)ext / 255.0, &ex);          // ext/255 = m * 2^ex, m in [0.5, 1)
+        e = std::max(1, std::min(254, ex + 127));
+        auto top = [&](int ee) { float st; uint32_t b = (uint32_t)ee << 23; std::memcpy(&st, &b, 4); return glo[a] + 255.0f * st; };
+        while (e < 254 && top(e) < ghi[a]) ++e;
+      }
+      float step; { uint32_t b = (uint32_t)e << 23; std::memcpy(&step, &b, 4); }
+      P.exps |= (uint32_t)e << (8 * a);
+      for (int k = 0; k < 4; ++k) {
+        uint32_t ql = 255, qh = 0;                              // unused slot (the entry says so)
+        if (!(q[k].leftFirst == kEmptySlot && q[k].count == 0)) {
+          double fl = std::floor(((double)q[k].lo[a] - (double)glo[a]) / (double)step);
+          double fh = std::ceil(((double)q[k].hi[a] - (double)glo[a]) / (double)step);
+          int il = (int)std::max(0.0, std::min(255.0, fl)), ih = (int)std::max(0.0, std::min(255.0, fh));
+          // make sure of the direction in fp32, as the kernel decodes: origin + q * step
+          while (il > 0 && glo[a] + (float)il * step > q[k].lo[a]) --il;
+          while (ih < 255 && glo[a] + (float)ih * step < q[k].hi[a]) ++ih;
+          ql = (uint32_t)il; qh = (uint32_t)ih;
+        }
+        planes[a] |= ql << (8 * k);
+        planes[3 + a] |= qh << (8 * k);
+      }
+    }
+    P.lox = planes[0]; P.loy = planes[1]; P.loz = planes[2]; P.hix = planes[3]; P.hiy = planes[4]; P.hiz = planes[5];
+    for (int k = 0; k < 4; ++k) {
+      const BvhNode& nd = q[k];
+      if (nd.leftFirst == kEmptySlot && nd.count == 0) P.entry[k] = kEmptySlot;
+      else if (nd.count) P.entry[k] = 0x80000000u | (nd.count << 28) | nd.leftFirst;
+      else P.entry[k] = nd.leftFirst;
+    }
+  }
+}
+
 }  // namespace rtx

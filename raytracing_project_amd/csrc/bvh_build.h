@@ -45,4 +45,23 @@ void build_bvh(const float* tri_lo, const float* tri_hi, uint32_t ntris, int thr
 // child group; ref == kEmptySlot unused.  Fills out->quads / quad_depth / quad_slots.
 void collapse_to_quads(BvhBuildResult* out);
 
+// 64-byte device encoding of one group (what the kernels actually load; half the bytes of the
+// fp32 layout, and the L1 return path is what bounds the traversal kernels): child boxes are
+// 8-bit fixed point relative to the group's own bounds, rounded outwards.
+//   origin[3]   group lower corner (fp32)
+//   exps        byte a = biased exponent of the power-of-two step of axis a (step = 2^(e-127))
+//   entry[4]    traversal entries: leaf = 0x80000000 | count << 28 | first triangle,
+//               internal = child group index, unused = 0xFFFFFFFF
+//   lox..hiz    byte k = child k's plane in steps from origin (lower planes rounded down,
+//               upper planes rounded up)
+struct PackedGroup {
+  float origin[3];
+  uint32_t exps;
+  uint32_t entry[4];
+  uint32_t lox, loy, loz, hix;
+  uint32_t hiy, hiz, pad0, pad1;
+};
+static_assert(sizeof(PackedGroup) == 64, "packed group must be 64 bytes");
+void pack_groups(const std::vector<BvhNode>& quads, std::vector<PackedGroup>* out);
+
 }  // namespace rtx

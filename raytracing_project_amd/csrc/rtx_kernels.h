@@ -10,13 +10,24 @@
 
 #include "rtx_math.h"
 
+#ifndef RTX_REFILL_MIN
+#define RTX_REFILL_MIN 16   // idle lanes of a wave before parked rays are handed out
+#endif
+#ifndef RTX_DEFER_MIN
+#define RTX_DEFER_MIN 16    // lanes at leaves before the triangle tests run (while node work exists)
+#endif
+
 namespace rtx {
+#ifdef RTX_DEBUG_TIMES
+__device__ unsigned long long g_dbg_times[2 * 16384];
+__device__ unsigned long long g_dbg_fetch[16384];
+#endif
 
 constexpr int kBlock = 256;          // 4 waves of 64
 constexpr int kStackDepth = 48;      // per-lane traversal stack entries in total (<= 3 per level of 4-node groups, <= 15 levels)
-constexpr int kLdsStack = 12;        // the first entries live in LDS (12 KB per block -> 8 waves/SIMD);
+constexpr int kLdsStack = 10;        // the first entries live in LDS (10 KB + 9 KB of parked rays per block -> 8 waves/SIMD);
+constexpr int kLdsStackGroups = 16;  // same for the group-by-group scheduler, which parks nothing
                                      // deeper ones (rare) spill to a per-thread global column
-constexpr uint32_t kMaxGrab = 256;   // most rays a wave takes from the work cursor per atomic
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kEmptyRef = 0xFFFFFFFFu;   // unused slot of a 4-node group
 constexpr float kPrecision = 0.001f; // Intersect::Face::precision (src/Intersect.h:14)
@@ -26,7 +37,7 @@ struct DevMat { float ka[3], kd[3], ks[3]; float ns, ni, d; int illum; int pad[3
 static_assert(sizeof(DevMat) == 64, "material record is 64 bytes");
 
 struct DevScene {
-  const float4* nodes;     // 2 x float4 per 32-byte node {lo.xyz, ref}, {hi.xyz, count}; groups of 4 siblings (128 B)
+  const uint4* nodes;      // 4 x uint4 per 64-byte packed group of 4 sibling nodes (PackedGroup, bvh_build.h)
   const float4* tris;      // 4 x float4 per leaf-ordered triangle: {v0,D} {u,uu} {v,uv} {n,vv}
   const int* tri_face;     // leaf order -> mesh face id
   const float4* face_nm;   // per mesh face: {query normal xyz, material id bits}
@@ -122,111 +133,60 @@ __device__ __forceinline__ void test_triangle(const DevScene& S, uint32_t k, V3 
   const float4 q0 = S.tris[4 * k];                 // v0, D
   const V3 n = v3(q3.x, q3.y, q3.z);
   const float den = dot(n, d);
-  if (den != 0.0f) {
-    const float t = (q0.w - dot(o, n)) / den;
-    if (t >= kPrecision && t <= best->t) {
-      const float4 q1 = S.tris[4 * k + 1];         // u, uu
-      const float4 q2 = S.tris[4 * k + 2];         // v, uv
-      const V3 P = point_on_ray(o, d, t);
-      const V3 w = P - v3(q0.x, q0.y, q0.z);
-      const float wu = dot(w, v3(q1.x, q1.y, q1.z)), wv = dot(w, v3(q2.x, q2.y, q2.z));
-      const float uu = q1.w, uv = q2.w, vv = q3.w;
-      const float denom = uu * vv - uv * uv;
-      const float s1 = vv * wu - uv * wv;
-      const float t1 = uu * wv - uv * wu;
-      const float s = s1 / denom;
-      const float tt = t1 / denom;
-      if (!(s < 0 || tt < 0 || s + tt > 1)) {
-        const int face = S.tri_face[k];
-        if (t < best->t || (t == best->t && face < best->id)) { best->t = t; best->id = face; }
-      }
-    }
+  if (den == 0.0f) return;
+  const float num = q0.w - dot(o, n);
+  // Cheap rejection first (hardware reciprocal, 1 ulp): a quotient clearly outside
+  // [precision, best] cannot pass the exact comparison below (margin 1e-5 >> 2^-22).
+  // (Only for |den| in the normal range, where the reciprocal is that accurate.)
+  const float tq = num * __builtin_amdgcn_rcpf(den);
+  if (fabsf(den) >= 1e-30f && !(tq >= kPrecision * 0.99999f && tq <= best->t * 1.00001f)) return;
+  const float t = num / den;
+  if (!(t >= kPrecision && t <= best->t)) return;
+  const float4 q1 = S.tris[4 * k + 1];             // u, uu
+  const float4 q2 = S.tris[4 * k + 2];             // v, uv
+  const V3 P = point_on_ray(o, d, t);
+  const V3 w = P - v3(q0.x, q0.y, q0.z);
+  const float wu = dot(w, v3(q1.x, q1.y, q1.z)), wv = dot(w, v3(q2.x, q2.y, q2.z));
+  const float uu = q1.w, uv = q2.w, vv = q3.w;
+  const float denom = uu * vv - uv * uv;
+  const float s1 = vv * wu - uv * wv;
+  const float t1 = uu * wv - uv * wu;
+  // Same idea for the barycentrics s = s1 / denom, tt = t1 / denom of the reference: for
+  // denom > 0 (every triangle outside the wild list), a numerator below -1e-30 * denom gives a
+  // quotient that is negative and not flushed to -0, and s1 + t1 > 1.00001 * denom gives
+  // s + tt > 1 after all three roundings; both are rejections of the exact test below.
+  if (denom > 0.0f && (s1 < -1e-30f * denom || t1 < -1e-30f * denom || s1 + t1 > 1.00001f * denom)) return;
+  const float s = s1 / denom;
+  const float tt = t1 / denom;
+  if (!(s < 0 || tt < 0 || s + tt > 1)) {
+    const int face = S.tri_face[k];
+    if (t < best->t || (t == best->t && face < best->id)) { best->t = t; best->id = face; }
   }
 }
 
 // Per-lane traversal stack: entries [0, kLdsStack) in LDS (column of this thread, stride
 // kBlock, so lane <-> bank and no conflicts), entries beyond in global memory (column of this
 // thread, stride = threads in the grid, so a wave's accesses to one level coalesce).
+typedef __attribute__((address_space(3))) uint32_t lds_u32;   // LDS word: 32-bit addresses, ds_* instructions
+// rank of this lane among the set bits of a wave mask (bits below the lane)
+__device__ __forceinline__ uint32_t lane_rank(uint64_t m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+template <int kLds>
 struct Stack {
-  uint32_t* lds;        // &lds_stack[threadIdx.x]
-  uint32_t* ovf;        // &overflow[global thread id]
-  uint32_t ovf_stride;
+  static constexpr int kLdsEntries = kLds;
+  lds_u32* lds;         // &lds_stack[threadIdx.x]
+  uint32_t* ovf;        // overflow base (uniform)
+  uint32_t ovf_col;     // global thread id = this thread's column
+  uint32_t ovf_stride;  // threads in the grid
   __device__ __forceinline__ void push(int sp, uint32_t v) const {
-    if (sp < kLdsStack) lds[sp * kBlock] = v;
-    else ovf[(size_t)(sp - kLdsStack) * ovf_stride] = v;
+    if (sp < kLds) lds[sp * kBlock] = v;
+    else ovf[(uint32_t)(sp - kLds) * ovf_stride + ovf_col] = v;
   }
   __device__ __forceinline__ uint32_t pop(int sp) const {
-    return sp < kLdsStack ? lds[sp * kBlock] : ovf[(size_t)(sp - kLdsStack) * ovf_stride];
+    return sp < kLds ? lds[sp * kBlock] : ovf[(uint32_t)(sp - kLds) * ovf_stride + ovf_col];
   }
 };
-
-// ---------------------------------------------------------------- closest hit
-// Flyscene::getIntersections (src/flyscene.cpp:517-585) for the ray Ray(o, .) whose stored
-// direction is d1.
-__device__ __forceinline__ Hit closest_hit(const DevScene& S, V3 o, V3 d1, const Stack& stk) {
-  Hit best; best.t = INFINITY; best.id = -1;
-  // spheres first, strict < (src/flyscene.cpp:523-532)
-  for (uint32_t i = 0; i < S.nspheres; ++i) {
-    float t = ref_sphere_t(o, d1, S.spheres[i]);
-    if (t != INFINITY && t < best.t) { best.t = t; best.id = -2 - (int)i; }
-  }
-  if (S.ntris == 0) return best;
-  // intersectBox / intersectTriangle rebuild the Ray, re-normalising d1 (src/flyscene.cpp:845,965)
-  const V3 d = normalized(d1);
-  if (!(S.flags & 1u) && !(ref_box_t(o, d, S.root_lo, S.root_hi) != INFINITY)) return best;
-
-  // slab constants for the padded BVH boxes (culling only; not part of the parity contract)
-  // |1/d| is clamped so that an axis-parallel ray gives huge finite slab distances of the
-  // right sign instead of inf - inf = NaN in the fused form below.
-  const float ivx = cull_inv(d.x), ivy = cull_inv(d.y), ivz = cull_inv(d.z);
-  const float oix = o.x * ivx, oiy = o.y * ivy, oiz = o.z * ivz;
-
-  for (uint32_t k = S.ntris - S.nwild; k < S.ntris; ++k) test_triangle(S, k, o, d, &best);
-  if (S.nwild == S.ntris) return best;
-
-  uint32_t cur = S.root_entry;
-  int sp = 0;
-  for (;;) {
-    if (!(cur & kLeafBit)) {
-      // one 128-byte group of 4 sibling nodes per step
-      const float4* q = S.nodes + 8 * (size_t)cur;
-      const float lim = best.t * kPruneSlack;
-      float tn[4]; uint32_t en[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float4 a = q[2 * k], b = q[2 * k + 1];
-        const float x0 = __builtin_fmaf(a.x, ivx, -oix), x1 = __builtin_fmaf(b.x, ivx, -oix);
-        const float y0 = __builtin_fmaf(a.y, ivy, -oiy), y1 = __builtin_fmaf(b.y, ivy, -oiy);
-        const float z0 = __builtin_fmaf(a.z, ivz, -oiz), z1 = __builtin_fmaf(b.z, ivz, -oiz);
-        const float n_ = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-        const float f_ = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-        const uint32_t ref = __float_as_uint(a.w), c = __float_as_uint(b.w);
-        const bool h = (n_ <= f_) && (f_ >= 0.0f) && (n_ <= lim) && (ref != kEmptyRef);
-        tn[k] = h ? n_ : INFINITY;
-        en[k] = c ? (kLeafBit | (c << 28) | ref) : ref;
-      }
-      // sort the 4 candidates near-to-far (5 compare-exchanges); misses carry tn = +inf
-#define RTX_CX(i, j) { const bool sw = tn[j] < tn[i]; const float tt_ = sw ? tn[j] : tn[i]; tn[j] = sw ? tn[i] : tn[j]; tn[i] = tt_; \
-                       const uint32_t ee_ = sw ? en[j] : en[i]; en[j] = sw ? en[i] : en[j]; en[i] = ee_; }
-      RTX_CX(0, 1) RTX_CX(2, 3) RTX_CX(0, 2) RTX_CX(1, 3) RTX_CX(1, 2)
-#undef RTX_CX
-      if (tn[0] != INFINITY) {
-        if (tn[3] != INFINITY) { stk.push(sp, en[3]); ++sp; }
-        if (tn[2] != INFINITY) { stk.push(sp, en[2]); ++sp; }
-        if (tn[1] != INFINITY) { stk.push(sp, en[1]); ++sp; }
-        cur = en[0];
-        continue;
-      }
-    } else {
-      const uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
-      for (uint32_t k = first; k < first + cnt; ++k) test_triangle(S, k, o, d, &best);
-    }
-    if (sp == 0) break;
-    --sp;
-    cur = stk.pop(sp);
-  }
-  return best;
-}
 
 // ---------------------------------------------------------------- camera rays
 // Camera::screenToWorld + Ray ctor (tucano/camera.hpp:155-173, src/flyscene.cpp:463-465)
@@ -279,72 +239,363 @@ __device__ __forceinline__ bool block_slot(const DevCamera& C, uint32_t block, u
 
 // ---------------------------------------------------------------- kernels
 // Persistent waves: the grid is sized to what is resident (8 blocks of 4 waves per CU) and
-// every wave takes `grab` consecutive ray indices at a time (struct Work), so expensive and
-// cheap regions of the image balance without any block-level synchronisation.
-__device__ __forceinline__ Stack make_stack(uint32_t* lds, uint32_t* ovf) {
-  Stack st;
-  st.lds = lds + threadIdx.x;
-  st.ovf = ovf + (size_t)blockIdx.x * kBlock + threadIdx.x;
+// every wave walks its own static sequence of 64-ray chunks (struct Work), so expensive and
+// cheap regions of the image balance without any block-level synchronisation or atomics.
+template <int kLds>
+__device__ __forceinline__ Stack<kLds> make_stack(uint32_t* lds, uint32_t* ovf) {
+  Stack<kLds> st;
+  st.lds = (lds_u32*)lds + threadIdx.x;
+  st.ovf = ovf;
+  st.ovf_col = blockIdx.x * kBlock + threadIdx.x;
   st.ovf_stride = gridDim.x * kBlock;
   return st;
 }
-// Work distribution.  RTX_WORK_STATIC (default): wave w of the grid takes the 64-ray groups
-// w, w + W, w + 2W, ... (W = waves in the grid) -- no atomics at all; every wave gets many
-// groups spread over the whole image, which averages the cost.  A single global cursor was
-// measured slower: at 64-192 rays per grab the ~40k atomics of a 4K frame serialise on one
-// L2 address (~88 dequeues/us), see DESIGN.md.
+// Work distribution over units of `grab` consecutive rays.
+//  * dynamic (counters != null): the units are cut into kRegions contiguous stripes, each with
+//    its own counter (one cache line each, so the atomics spread over L2 channels instead of
+//    serialising on one address).  Counter k belongs to XCD k / 8 (blocks go round-robin over
+//    the 8 XCDs) and covers stripe (k % 8) * 8 + k / 8, so every XCD starts with 8 stripes
+//    spread over the whole range and neighbouring rays meet in one L2.  A wave keeps taking
+//    units from its current stripe (one atomic, ~1 us against ~100 us of traversal per unit);
+//    when that runs dry it reads all 64 counters with one vector load and moves to the next
+//    stripe that still has units, its own XCD's first.
+//  * static (counters == null): wave w takes units w, w + W, w + 2W, ...; no atomics, but the
+//    waves of a frame finish far apart (mean wave busy time 57-67% of the kernel, measured).
+constexpr uint32_t kRegions = 64;         // == lanes of a wave (one lane per counter in the scan)
+constexpr uint32_t kCounterStride = 32;   // words between counters (128 B)
 struct Work {
-  uint32_t n, grab, next_base, step;
+  uint32_t n, grab;
+  uint32_t next_base, step;                       // static
+  uint32_t* counters;                             // dynamic
+  uint32_t nunits, per_region, k;                 // k = current counter
+  __device__ __forceinline__ uint32_t stripe_of(uint32_t kk) const { return (kk & 7u) * 8u + (kk >> 3); }
   __device__ __forceinline__ bool next(uint32_t* base) {
-    *base = next_base;
-    next_base += step;
-    return *base < n;
+    if (counters == nullptr) {
+      *base = next_base;
+      next_base += step;
+      return *base < n;
+    }
+    const uint32_t lane = threadIdx.x & 63;
+#ifdef RTX_DEBUG_TIMES
+    const unsigned long long tf0 = wall_clock64();
+    struct Acc { unsigned long long t0; __device__ ~Acc() { const uint32_t w_ = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+      if ((threadIdx.x & 63) == 0 && w_ < 16384) g_dbg_fetch[w_] += wall_clock64() - t0; } } acc{tf0};
+#endif
+    for (;;) {
+      uint32_t i = 0;
+      if (lane == 0) i = atomicAdd(counters + k * kCounterStride, 1u);
+      i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+      const uint32_t u = stripe_of(k) * per_region + i;
+      if (i < per_region && u < nunits) { *base = u * grab; return true; }
+      // dry: one look at all counters (lane = counter; loaded past the L1, which the atomics bypass)
+      const uint32_t seen = __hip_atomic_load(counters + lane * kCounterStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t first = stripe_of(lane) * per_region;
+      const bool has = seen < per_region && first + seen < nunits;
+      const uint64_t avail = __ballot(has);
+      if (avail == 0) return false;
+      const uint64_t rot = (avail >> k) | (k ? avail << (64u - k) : 0ull);   // bit t = counter (k + t) % 64
+      k = (k + (uint32_t)__builtin_ctzll(rot)) & 63u;
+    }
   }
 };
-__device__ __forceinline__ Work make_work(uint32_t* /*cursor*/, uint32_t n, uint32_t grab) {
-  Work w; w.n = n; w.grab = grab;
-  w.next_base = (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * grab;
+__device__ __forceinline__ Work make_work(uint32_t n, uint32_t grab, uint32_t* counters) {
+  Work w; w.n = n; w.grab = grab; w.counters = counters;
+  w.next_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * grab));
   w.step = gridDim.x * (kBlock / 64) * grab;
+  w.nunits = (n + grab - 1) / grab;
+  w.per_region = (w.nunits + kRegions - 1) / kRegions;
+  w.k = (blockIdx.x & 7u) * 8u + ((blockIdx.x >> 3) & 7u);
   return w;
 }
 
-// Camera rays of a pixel rectangle.  Ray index j = (16x16 pixel block, thread): consecutive
-// indices walk 8x8 pixel sub-tiles, so the 64 rays of a wave stay coherent.  Writes {t, id}.
-__global__ __launch_bounds__(kBlock, 8) void k_trace_camera(DevScene S, DevCamera C, uint32_t nblocks, uint32_t grab, uint32_t* cursor,
-                                                          uint32_t* ovf, uint2* hits) {
-  __shared__ uint32_t lds_stack[kLdsStack * kBlock];
-  const Stack stk = make_stack(lds_stack, ovf);
-  const uint32_t n = nblocks * (uint32_t)kBlock;
-  Work work = make_work(cursor, n, grab);
-  uint32_t base;
-  while (work.next(&base)) {
-    const uint32_t end = base + grab < n ? base + grab : n;
-    for (uint32_t j = base + (threadIdx.x & 63); j < end; j += 64) {
-      int lx, ly; uint32_t slot;
-      if (!block_slot(C, j / kBlock, j % kBlock, &slot, &lx, &ly)) continue;
-      V3 o, d1;
-      camera_ray(C, C.x0 + lx, C.y0 + ly, &o, &d1);
-      const Hit h = closest_hit(S, o, d1, stk);
-      hits[slot] = make_uint2(__float_as_uint(h.t), (uint32_t)h.id);
+// One traversal step over the packed group of 4 sibling nodes *cur: slab tests against the
+// padded (and outward-quantised) boxes, near-to-far order, the other hits pushed far-to-near.  Returns false when no
+// child is hit (the caller pops); else *cur = the nearest child.
+template <class StackT>
+__device__ __forceinline__ bool node_step(const DevScene& S, const StackT& stk, float lim, float ivx, float ivy, float ivz, float oix,
+                                          float oiy, float oiz, uint32_t* cur, int* sp_io) {
+  int sp = *sp_io;
+  // one 64-byte packed group of 4 sibling nodes per step (uniform base + 32-bit byte offset)
+  const uint4* q = (const uint4*)((const char*)S.nodes + (*cur << 6));
+  const uint4 h0 = q[0], h1 = q[1], h2 = q[2], h3 = q[3];
+  // planes are origin + byte * 2^(e-127) per axis; fold origin, step and the ray into one fma per plane
+  const float ax = __uint_as_float((h0.w & 0xFFu) << 23) * ivx;
+  const float ay = __uint_as_float(((h0.w >> 8) & 0xFFu) << 23) * ivy;
+  const float az = __uint_as_float(((h0.w >> 16) & 0xFFu) << 23) * ivz;
+  const float bx = __builtin_fmaf(__uint_as_float(h0.x), ivx, -oix);
+  const float by = __builtin_fmaf(__uint_as_float(h0.y), ivy, -oiy);
+  const float bz = __builtin_fmaf(__uint_as_float(h0.z), ivz, -oiz);
+  const uint32_t ents[4] = {h1.x, h1.y, h1.z, h1.w};
+  float tn[4]; uint32_t en[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int sh = 8 * k;
+    const float x0 = __builtin_fmaf((float)((h2.x >> sh) & 0xFFu), ax, bx), x1 = __builtin_fmaf((float)((h2.w >> sh) & 0xFFu), ax, bx);
+    const float y0 = __builtin_fmaf((float)((h2.y >> sh) & 0xFFu), ay, by), y1 = __builtin_fmaf((float)((h3.x >> sh) & 0xFFu), ay, by);
+    const float z0 = __builtin_fmaf((float)((h2.z >> sh) & 0xFFu), az, bz), z1 = __builtin_fmaf((float)((h3.y >> sh) & 0xFFu), az, bz);
+    // entry clamped to the ray start, exit to the pruning limit: hit <=> entry <= exit
+    const float n_ = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+    const float f_ = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), lim));
+    en[k] = ents[k];
+    tn[k] = ((n_ <= f_) && (en[k] != kEmptyRef)) ? n_ : INFINITY;
+  }
+  // sort the 4 candidates near-to-far (5 compare-exchanges); misses carry tn = +inf
+#define RTX_CX(i, j) { const bool sw = tn[j] < tn[i]; const float tt_ = sw ? tn[j] : tn[i]; tn[j] = sw ? tn[i] : tn[j]; tn[i] = tt_; \
+                   const uint32_t ee_ = sw ? en[j] : en[i]; en[j] = sw ? en[i] : en[j]; en[i] = ee_; }
+  RTX_CX(0, 1) RTX_CX(2, 3) RTX_CX(0, 2) RTX_CX(1, 3) RTX_CX(1, 2)
+#undef RTX_CX
+  // far-to-near pushes of the other hits.  Fast path: three unconditional LDS stores, the
+  // stack pointer only advances over the real ones (a miss is overwritten by the next store
+  // or left above the top).
+  if (sp <= StackT::kLdsEntries - 3) {
+    stk.lds[sp * kBlock] = en[3]; sp += (tn[3] != INFINITY) ? 1 : 0;
+    stk.lds[sp * kBlock] = en[2]; sp += (tn[2] != INFINITY) ? 1 : 0;
+    stk.lds[sp * kBlock] = en[1]; sp += (tn[1] != INFINITY) ? 1 : 0;
+  } else {
+    if (tn[3] != INFINITY) { stk.push(sp, en[3]); ++sp; }
+    if (tn[2] != INFINITY) { stk.push(sp, en[2]); ++sp; }
+    if (tn[1] != INFINITY) { stk.push(sp, en[1]); ++sp; }
+  }
+  *sp_io = sp;
+  if (tn[0] == INFINITY) return false;
+  *cur = en[0];
+  return true;
+}
+
+// Where a wave's rays come from.  get(j): ray j of the launch -> origin, Ray direction d1 and
+// the output slot of its hit record; false where index j holds no ray.
+struct CameraSource {
+  DevCamera C;
+  __device__ __forceinline__ bool get(uint32_t j, V3* o, V3* d1, uint32_t* slot) const {
+    int lx, ly;
+    if (!block_slot(C, j / kBlock, j % kBlock, slot, &lx, &ly)) return false;
+    camera_ray(C, C.x0 + lx, C.y0 + ly, o, d1);
+    return true;
+  }
+};
+struct QueueSource {
+  const float4* rays;
+  __device__ __forceinline__ bool get(uint32_t j, V3* o, V3* d1, uint32_t* slot) const {
+    const float4 ro = rays[2 * (size_t)j], rd = rays[2 * (size_t)j + 1];
+    *o = v3(ro.x, ro.y, ro.z); *d1 = v3(rd.x, rd.y, rd.z); *slot = j;
+    return true;
+  }
+};
+
+// ---------------------------------------------------------------- closest hit, one wave
+// Flyscene::getIntersections (src/flyscene.cpp:517-585) for a stream of rays, scheduled for
+// a 64-wide wave:
+//  * setup (spheres, the Ray re-normalisation, the reference's root-box gate, the "wild"
+//    triangles) runs for 64 rays at a time with all lanes busy; rays that still need the BVH
+//    are parked in a small per-wave LDS buffer (wbuf, 9 words x 64);
+//  * lanes whose ray has finished take a parked ray (refill) once kRefillMin lanes are idle,
+//    instead of idling until the slowest ray of a 64-ray group is done;
+//  * a lane that reaches a leaf waits until kDeferMin lanes are at leaves (or no lane has a
+//    node to do), so that the expensive triangle tests run with more lanes active.
+// None of this changes what is computed per ray: each ray still sees its nodes and triangles
+// in the same order; scripts/wave_sim.py replays traversal logs under these policies.
+constexpr uint32_t kDone = 0x7FFFFFFFu;   // lane holds no ray (never a valid entry: group indices stay below 2^25)
+constexpr int kRefillMin = RTX_REFILL_MIN;
+constexpr int kDeferMin = RTX_DEFER_MIN;
+constexpr int kWbufWords = 9;             // o.xyz, d.xyz, best.t, best.id, slot
+
+template <class Source>
+__device__ __forceinline__ void trace_wave(const DevScene& S, const Source& src, Work work, const Stack<kLdsStack>& stk, lds_u32* wbuf,
+                                           uint2* hits) {
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t nbuf = 0;                       // parked rays (wave-uniform)
+  uint32_t chunk = 0, chunk_end = 0;       // rest of the current grab (wave-uniform)
+  bool more = true;
+  V3 o = v3(0, 0, 0), d = v3(0, 0, 0);
+  float ivx = 0, ivy = 0, ivz = 0, oix = 0, oiy = 0, oiz = 0;
+  Hit best; best.t = INFINITY; best.id = -1;
+  uint32_t cur = kDone, slot = 0;
+  int sp = 0;
+
+  for (;;) {
+    // entry kinds: leaf = top bit set, node group = below kDone, no ray = kDone
+    uint64_t act = __ballot(cur != kDone);
+    const uint32_t nidle = 64u - (uint32_t)__popcll(act);
+    if ((nidle >= (uint32_t)kRefillMin || act == 0) && (nbuf != 0 || more)) {
+      while (nbuf == 0 && more) {
+        if (chunk >= chunk_end) {
+          uint32_t base;
+          more = work.next(&base);
+          if (!more) break;
+          chunk = base;
+          chunk_end = base + work.grab < work.n ? base + work.grab : work.n;
+        }
+        const uint32_t j = chunk + lane;
+        chunk += 64;
+        // ---- setup of ray j on every lane
+        V3 so, sd1; uint32_t sslot = 0;
+        bool park = false;
+        Hit sb; sb.t = INFINITY; sb.id = -1;
+        V3 sd = v3(0, 0, 0);
+        if (j < chunk_end && src.get(j, &so, &sd1, &sslot)) {
+          // spheres first, strict < (src/flyscene.cpp:523-532)
+          for (uint32_t i = 0; i < S.nspheres; ++i) {
+            const float t = ref_sphere_t(so, sd1, S.spheres[i]);
+            if (t != INFINITY && t < sb.t) { sb.t = t; sb.id = -2 - (int)i; }
+          }
+          if (S.ntris != 0) {
+            // intersectBox / intersectTriangle rebuild the Ray, re-normalising d1 (src/flyscene.cpp:845,965)
+            sd = normalized(sd1);
+            if ((S.flags & 1u) || ref_box_t(so, sd, S.root_lo, S.root_hi) != INFINITY) {
+              for (uint32_t k = S.ntris - S.nwild; k < S.ntris; ++k) test_triangle(S, k, so, sd, &sb);
+              park = S.nwild != S.ntris;
+            }
+          }
+          if (!park) hits[sslot] = make_uint2(__float_as_uint(sb.t), (uint32_t)sb.id);
+        }
+        const uint64_t pm = __ballot(park);
+        if (park) {
+          lds_u32* w = wbuf + lane_rank(pm);
+          w[0] = __float_as_uint(so.x); w[64] = __float_as_uint(so.y); w[128] = __float_as_uint(so.z);
+          w[192] = __float_as_uint(sd.x); w[256] = __float_as_uint(sd.y); w[320] = __float_as_uint(sd.z);
+          w[384] = __float_as_uint(sb.t); w[448] = (uint32_t)sb.id; w[512] = sslot;
+        }
+        nbuf = (uint32_t)__popcll(pm);
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (nbuf != 0) {
+        const uint32_t r = lane_rank(~act);      // rank among the idle lanes
+        if (cur == kDone && r < nbuf) {
+          const lds_u32* w = wbuf + (nbuf - 1u - r);
+          o = v3(__uint_as_float(w[0]), __uint_as_float(w[64]), __uint_as_float(w[128]));
+          d = v3(__uint_as_float(w[192]), __uint_as_float(w[256]), __uint_as_float(w[320]));
+          best.t = __uint_as_float(w[384]); best.id = (int)w[448]; slot = w[512];
+          // slab constants for the padded BVH boxes (culling only; not part of the parity
+          // contract).  |1/d| is clamped so that an axis-parallel ray gives huge finite slab
+          // distances of the right sign instead of inf - inf = NaN in the fused form below.
+          ivx = cull_inv(d.x); ivy = cull_inv(d.y); ivz = cull_inv(d.z);
+          oix = o.x * ivx; oiy = o.y * ivy; oiz = o.z * ivz;
+          cur = S.root_entry; sp = 0;
+        }
+        nbuf -= nidle < nbuf ? nidle : nbuf;
+        __builtin_amdgcn_wave_barrier();
+      }
+      act = __ballot(cur != kDone);
+    }
+    if (act == 0) break;                   // no ray in flight, nothing parked, nothing left to set up
+
+    const bool at_leaf = (int)cur < 0;
+    const bool at_node = cur < kDone;
+    const uint64_t leaf_mask = __ballot(at_leaf);
+    const bool any_node = (act & ~leaf_mask) != 0;
+    bool pop = false;
+    if (at_node) {
+      pop = !node_step(S, stk, best.t * kPruneSlack, ivx, ivy, ivz, oix, oiy, oiz, &cur, &sp);
+    }
+    if (leaf_mask != 0 && (!any_node || __popcll(leaf_mask) >= kDeferMin)) {
+      if (at_leaf) {
+        const uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
+        for (uint32_t k = first; k < first + cnt; ++k) test_triangle(S, k, o, d, &best);
+        pop = true;
+      }
+    }
+    if (pop) {
+      if (sp == 0) {
+        hits[slot] = make_uint2(__float_as_uint(best.t), (uint32_t)best.id);
+        cur = kDone;
+      } else {
+        --sp;
+        cur = stk.pop(sp);
+      }
     }
   }
 }
 
-// Queued rays: rays[2i] = {o.xyz, aux}, rays[2i+1] = {d1.xyz, aux}; *count * stride rays.
-__global__ __launch_bounds__(kBlock, 8) void k_trace_queue(DevScene S, const float4* rays, const uint32_t* count, uint32_t stride,
-                                                         uint32_t grab, uint32_t* cursor, uint32_t* ovf, uint2* hits) {
-  __shared__ uint32_t lds_stack[kLdsStack * kBlock];
-  const Stack stk = make_stack(lds_stack, ovf);
-  const uint32_t n = *count * stride;
-  Work work = make_work(cursor, n, grab);
+// The same per-ray work scheduled group by group: a wave sets 64 rays up, walks them until the
+// slowest is done, then takes the next 64.  No parking, no refill, no deferral -- less
+// bookkeeping per step, which wins where the rays of a group stay in step (coherent rays on
+// closed surfaces); the refilling scheduler above wins on incoherent work (triangle soups,
+// diffuse bounces).
+template <class Source>
+__device__ __forceinline__ void trace_wave_groups(const DevScene& S, const Source& src, Work work, const Stack<kLdsStackGroups>& stk,
+                                                  uint2* hits) {
+  const uint32_t lane = threadIdx.x & 63;
   uint32_t base;
   while (work.next(&base)) {
-    const uint32_t end = base + grab < n ? base + grab : n;
-    for (uint32_t j = base + (threadIdx.x & 63); j < end; j += 64) {
-      const float4 ro = rays[2 * (size_t)j], rd = rays[2 * (size_t)j + 1];
-      const Hit h = closest_hit(S, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), stk);
-      hits[j] = make_uint2(__float_as_uint(h.t), (uint32_t)h.id);
+    const uint32_t end = base + work.grab < work.n ? base + work.grab : work.n;
+    for (uint32_t j = base + lane; j < end; j += 64) {
+      V3 o, d1; uint32_t slot;
+      if (!src.get(j, &o, &d1, &slot)) continue;
+      Hit best; best.t = INFINITY; best.id = -1;
+      for (uint32_t i = 0; i < S.nspheres; ++i) {
+        const float t = ref_sphere_t(o, d1, S.spheres[i]);
+        if (t != INFINITY && t < best.t) { best.t = t; best.id = -2 - (int)i; }
+      }
+      bool walk = false;
+      V3 d = v3(0, 0, 0);
+      if (S.ntris != 0) {
+        d = normalized(d1);
+        if ((S.flags & 1u) || ref_box_t(o, d, S.root_lo, S.root_hi) != INFINITY) {
+          for (uint32_t k = S.ntris - S.nwild; k < S.ntris; ++k) test_triangle(S, k, o, d, &best);
+          walk = S.nwild != S.ntris;
+        }
+      }
+      if (walk) {
+        const float ivx = cull_inv(d.x), ivy = cull_inv(d.y), ivz = cull_inv(d.z);
+        const float oix = o.x * ivx, oiy = o.y * ivy, oiz = o.z * ivz;
+        uint32_t cur = S.root_entry;
+        int sp = 0;
+        for (;;) {
+          if ((int)cur >= 0) {
+            if (node_step(S, stk, best.t * kPruneSlack, ivx, ivy, ivz, oix, oiy, oiz, &cur, &sp)) continue;
+          } else {
+            const uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
+            for (uint32_t k = first; k < first + cnt; ++k) test_triangle(S, k, o, d, &best);
+          }
+          if (sp == 0) break;
+          --sp;
+          cur = stk.pop(sp);
+        }
+      }
+      hits[slot] = make_uint2(__float_as_uint(best.t), (uint32_t)best.id);
     }
+  }
+}
+
+#ifdef RTX_DEBUG_TIMES
+#define RTX_DBG_BEGIN const unsigned long long dbg_t0_ = wall_clock64();
+#define RTX_DBG_END { const uint32_t w_ = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); \
+    if ((threadIdx.x & 63) == 0 && w_ < 16384) { g_dbg_times[2 * w_] = dbg_t0_; g_dbg_times[2 * w_ + 1] = wall_clock64(); } }
+#else
+#define RTX_DBG_BEGIN
+#define RTX_DBG_END
+#endif
+
+// Camera rays of a pixel rectangle.  Ray index j = (16x16 pixel block, thread): consecutive
+// indices walk 8x8 pixel sub-tiles, so the 64 rays of a chunk are coherent.  Writes {t, id}.
+template <bool kRefill>
+__global__ __launch_bounds__(kBlock, 8) void k_trace_camera(DevScene S, DevCamera C, uint32_t nblocks, uint32_t grab, uint32_t* counters,
+                                                          uint32_t* ovf, uint2* hits) {
+  __shared__ uint32_t lds_stack[(kRefill ? kLdsStack : kLdsStackGroups) * kBlock];
+  RTX_DBG_BEGIN
+  CameraSource src; src.C = C;
+  const Work work = make_work(nblocks * (uint32_t)kBlock, grab, counters);
+  if constexpr (kRefill) {
+    __shared__ uint32_t lds_wbuf[(kBlock / 64) * kWbufWords * 64];
+    trace_wave(S, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), hits);
+  } else {
+    trace_wave_groups(S, src, work, make_stack<kLdsStackGroups>(lds_stack, ovf), hits);
+  }
+  RTX_DBG_END
+}
+
+// Queued rays: rays[2i] = {o.xyz, aux}, rays[2i+1] = {d1.xyz, aux}; *count * stride rays.
+template <bool kRefill>
+__global__ __launch_bounds__(kBlock, 8) void k_trace_queue(DevScene S, const float4* rays, const uint32_t* count, uint32_t stride,
+                                                         uint32_t grab, uint32_t* counters, uint32_t* ovf, uint2* hits) {
+  __shared__ uint32_t lds_stack[(kRefill ? kLdsStack : kLdsStackGroups) * kBlock];
+  QueueSource src; src.rays = rays;
+  const Work work = make_work(*count * stride, grab, counters);
+  if constexpr (kRefill) {
+    __shared__ uint32_t lds_wbuf[(kBlock / 64) * kWbufWords * 64];
+    trace_wave(S, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), hits);
+  } else {
+    trace_wave_groups(S, src, work, make_stack<kLdsStackGroups>(lds_stack, ovf), hits);
   }
 }
 
