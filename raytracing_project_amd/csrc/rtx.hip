@@ -93,8 +93,6 @@ struct rtx_scene {
   DevBuf d_slights, d_leafboxes, d_leaf_faces, d_face_pos;
   // workspace
   DevBuf w_stack_ovf;                // global overflow columns of the per-lane traversal stacks
-  DevBuf w_counters_work;            // kMaxTraceLaunches x kRegions work counters (zeroed at the start of a call)
-  uint32_t trace_launches = 0;
   DevBuf w_rays[2], w_hits[2], w_parents, w_shadow_rays, w_shadow_hits, w_gi_rays, w_gi_hits, w_counters, w_io[6];
   EventPool events;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_spans, all_spans;
@@ -104,8 +102,6 @@ struct rtx_scene {
   int ncu = 256;
 };
 
-constexpr uint32_t kMaxTraceLaunches = 64;
-constexpr size_t kWorkCounterBytes = (size_t)kMaxTraceLaunches * kRegions * kCounterStride * 4;
 static int trace_grid(const rtx_scene* s) { return s->ncu * 8; }      // 8 blocks x 4 waves = 32 waves per CU
 
 extern "C" const char* rtx_last_error(void) { return g_err.c_str(); }
@@ -136,7 +132,7 @@ static void release_device(rtx_scene* s) {
   if (s->device >= 0) (void)hipSetDevice(s->device);
   DevBuf* bufs[] = {&s->d_nodes, &s->d_tris, &s->d_tri_face, &s->d_face_nm, &s->d_spheres, &s->d_sph_mat, &s->d_mats,
                     &s->d_lights, &s->d_slights, &s->d_leafboxes, &s->d_leaf_faces, &s->d_face_pos, &s->w_gi_rays,
-                    &s->w_gi_hits, &s->w_stack_ovf, &s->w_counters_work, &s->w_rays[0], &s->w_rays[1], &s->w_hits[0], &s->w_hits[1], &s->w_parents,
+                    &s->w_gi_hits, &s->w_stack_ovf, &s->w_rays[0], &s->w_rays[1], &s->w_hits[0], &s->w_hits[1], &s->w_parents,
                     &s->w_shadow_rays, &s->w_shadow_hits, &s->w_counters, &s->w_io[0], &s->w_io[1], &s->w_io[2],
                     &s->w_io[3], &s->w_io[4], &s->w_io[5]};
   for (DevBuf* b : bufs) b->release();
@@ -512,8 +508,6 @@ static void span_end(rtx_scene* s, bool trace) {
   (void)hipEventRecord((trace ? s->trace_spans : s->all_spans).back().second, s->stream);
 }
 static void stats_begin(rtx_scene* s) {
-  s->trace_launches = 0;
-  if (s->w_counters_work.ensure(kWorkCounterBytes) == 0) (void)hipMemsetAsync(s->w_counters_work.p, 0, kWorkCounterBytes, s->stream);
   s->events.reset(); s->trace_spans.clear(); s->all_spans.clear(); s->camera_span = (size_t)-1;
   std::memset(&s->stats, 0, sizeof s->stats);
   span_begin(s, false);
@@ -554,46 +548,37 @@ static uint32_t grab_size() {
   return g;
 }
 // Scheduler per launch kind: RTX_SCHED = "refill" | "groups" | unset (default below).
-static bool sched_refill(bool camera) {
+static bool sched_refill(const rtx_scene* s, bool camera, uint64_t rays) {
   static const int forced = [] {
     const char* e = std::getenv("RTX_SCHED");
     if (!e) return -1;
     return std::strcmp(e, "refill") == 0 ? 1 : std::strcmp(e, "groups") == 0 ? 0 : -1;
   }();
   if (forced >= 0) return forced == 1;
-  (void)camera;
-  return true;
-}
-// Work counters of the next traversal launch of this call; null = static distribution.
-static int next_counters(rtx_scene* s, uint32_t** out) {
-  static const bool dynamic = [] { const char* e = std::getenv("RTX_WORK"); return !(e && std::strcmp(e, "static") == 0); }();
-  if (!dynamic) { *out = nullptr; return RTX_OK; }
-  if (s->trace_launches >= kMaxTraceLaunches) return fail(RTX_ELIMIT, "too many traversal launches in one call");
-  *out = s->w_counters_work.as<uint32_t>() + (size_t)s->trace_launches++ * kRegions * kCounterStride;
-  return RTX_OK;
+  // Measured: the refilling scheduler wins on queued rays (shadow / bounce rays:
+  // incoherent) and on camera rays once a wave has many 64-ray units to draw from (4K frames);
+  // group by group wins on the coherent camera rays of smaller frames.
+  if (!camera) return true;
+  return rays >= (uint64_t)trace_grid(s) * (kBlock / 64) * 64 * 8;
 }
 static int launch_trace_camera(rtx_scene* s, const DevCamera& C, uint32_t tiles, uint2* hits) {
-  uint32_t* ctr;
-  if (int rc = next_counters(s, &ctr)) return rc;
   const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(tiles, 1), (uint32_t)trace_grid(s));
-  if (sched_refill(true))
-    hipLaunchKernelGGL(k_trace_camera<true>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, C, tiles, grab_size(), ctr,
+  if (sched_refill(s, true, (uint64_t)tiles * kBlock))
+    hipLaunchKernelGGL(k_trace_camera<true>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, C, tiles, grab_size(),
                        s->w_stack_ovf.as<uint32_t>(), hits);
   else
-    hipLaunchKernelGGL(k_trace_camera<false>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, C, tiles, grab_size(), ctr,
+    hipLaunchKernelGGL(k_trace_camera<false>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, C, tiles, grab_size(),
                        s->w_stack_ovf.as<uint32_t>(), hits);
   return RTX_OK;
 }
 static int launch_trace_queue(rtx_scene* s, const float4* rays, const uint32_t* count, uint32_t stride, uint64_t bound, uint2* hits) {
-  uint32_t* ctr;
-  if (int rc = next_counters(s, &ctr)) return rc;
   const uint64_t blocks = (bound * stride + kBlock - 1) / kBlock;
   const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, (uint64_t)trace_grid(s)));
-  if (sched_refill(false))
-    hipLaunchKernelGGL(k_trace_queue<true>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride, grab_size(), ctr,
+  if (sched_refill(s, false, bound * stride))
+    hipLaunchKernelGGL(k_trace_queue<true>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride, grab_size(),
                        s->w_stack_ovf.as<uint32_t>(), hits);
   else
-    hipLaunchKernelGGL(k_trace_queue<false>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride, grab_size(), ctr,
+    hipLaunchKernelGGL(k_trace_queue<false>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride, grab_size(),
                        s->w_stack_ovf.as<uint32_t>(), hits);
   return RTX_OK;
 }
@@ -977,17 +962,3 @@ extern "C" int rtx_get_stats(const rtx_scene* s, rtx_stats* out) {
   *out = s->stats;
   return RTX_OK;
 }
-
-#ifdef RTX_DEBUG_TIMES
-// diagnostic build only: per-wave {start, end} wall-clock ticks (100 MHz) of the last camera launch
-extern "C" int rtx_debug_wave_times(unsigned long long* out, unsigned n) {
-  if (n > 2 * 16384) n = 2 * 16384;
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rtx::g_dbg_times), (size_t)n * 8);
-}
-extern "C" int rtx_debug_fetch_times(unsigned long long* out, unsigned n, int reset) {
-  if (n > 16384) n = 16384;
-  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rtx::g_dbg_fetch), (size_t)n * 8);
-  if (reset) { static unsigned long long z[16384]; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(rtx::g_dbg_fetch), z, sizeof z); }
-  return rc;
-}
-#endif

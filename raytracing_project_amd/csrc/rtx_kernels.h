@@ -18,10 +18,6 @@
 #endif
 
 namespace rtx {
-#ifdef RTX_DEBUG_TIMES
-__device__ unsigned long long g_dbg_times[2 * 16384];
-__device__ unsigned long long g_dbg_fetch[16384];
-#endif
 
 constexpr int kBlock = 256;          // 4 waves of 64
 constexpr int kStackDepth = 48;      // per-lane traversal stack entries in total (<= 3 per level of 4-node groups, <= 15 levels)
@@ -250,61 +246,24 @@ __device__ __forceinline__ Stack<kLds> make_stack(uint32_t* lds, uint32_t* ovf) 
   st.ovf_stride = gridDim.x * kBlock;
   return st;
 }
-// Work distribution over units of `grab` consecutive rays.
-//  * dynamic (counters != null): the units are cut into kRegions contiguous stripes, each with
-//    its own counter (one cache line each, so the atomics spread over L2 channels instead of
-//    serialising on one address).  Counter k belongs to XCD k / 8 (blocks go round-robin over
-//    the 8 XCDs) and covers stripe (k % 8) * 8 + k / 8, so every XCD starts with 8 stripes
-//    spread over the whole range and neighbouring rays meet in one L2.  A wave keeps taking
-//    units from its current stripe (one atomic, ~1 us against ~100 us of traversal per unit);
-//    when that runs dry it reads all 64 counters with one vector load and moves to the next
-//    stripe that still has units, its own XCD's first.
-//  * static (counters == null): wave w takes units w, w + W, w + 2W, ...; no atomics, but the
-//    waves of a frame finish far apart (mean wave busy time 57-67% of the kernel, measured).
-constexpr uint32_t kRegions = 64;         // == lanes of a wave (one lane per counter in the scan)
-constexpr uint32_t kCounterStride = 32;   // words between counters (128 B)
+// Work distribution: wave w of the grid takes the `grab`-ray units w, w + W, w + 2W, ...
+// (W = waves in the grid) -- no atomics.  Measured alternatives: one global cursor
+// (agent-scope atomics run at ~90 per us on this part whatever the address, and serialise),
+// and 64 per-stripe counters with XCD-local homes (better balance, mean wave busy time 67% ->
+// 85% of the kernel, but no faster: the kernels are bound by the L1 return path, which the
+// early-finishing waves leave to the others).
 struct Work {
-  uint32_t n, grab;
-  uint32_t next_base, step;                       // static
-  uint32_t* counters;                             // dynamic
-  uint32_t nunits, per_region, k;                 // k = current counter
-  __device__ __forceinline__ uint32_t stripe_of(uint32_t kk) const { return (kk & 7u) * 8u + (kk >> 3); }
+  uint32_t n, grab, next_base, step;
   __device__ __forceinline__ bool next(uint32_t* base) {
-    if (counters == nullptr) {
-      *base = next_base;
-      next_base += step;
-      return *base < n;
-    }
-    const uint32_t lane = threadIdx.x & 63;
-#ifdef RTX_DEBUG_TIMES
-    const unsigned long long tf0 = wall_clock64();
-    struct Acc { unsigned long long t0; __device__ ~Acc() { const uint32_t w_ = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-      if ((threadIdx.x & 63) == 0 && w_ < 16384) g_dbg_fetch[w_] += wall_clock64() - t0; } } acc{tf0};
-#endif
-    for (;;) {
-      uint32_t i = 0;
-      if (lane == 0) i = atomicAdd(counters + k * kCounterStride, 1u);
-      i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
-      const uint32_t u = stripe_of(k) * per_region + i;
-      if (i < per_region && u < nunits) { *base = u * grab; return true; }
-      // dry: one look at all counters (lane = counter; loaded past the L1, which the atomics bypass)
-      const uint32_t seen = __hip_atomic_load(counters + lane * kCounterStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t first = stripe_of(lane) * per_region;
-      const bool has = seen < per_region && first + seen < nunits;
-      const uint64_t avail = __ballot(has);
-      if (avail == 0) return false;
-      const uint64_t rot = (avail >> k) | (k ? avail << (64u - k) : 0ull);   // bit t = counter (k + t) % 64
-      k = (k + (uint32_t)__builtin_ctzll(rot)) & 63u;
-    }
+    *base = next_base;
+    next_base += step;
+    return *base < n;
   }
 };
-__device__ __forceinline__ Work make_work(uint32_t n, uint32_t grab, uint32_t* counters) {
-  Work w; w.n = n; w.grab = grab; w.counters = counters;
+__device__ __forceinline__ Work make_work(uint32_t n, uint32_t grab) {
+  Work w; w.n = n; w.grab = grab;
   w.next_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * grab));
   w.step = gridDim.x * (kBlock / 64) * grab;
-  w.nunits = (n + grab - 1) / grab;
-  w.per_region = (w.nunits + kRegions - 1) / kRegions;
-  w.k = (blockIdx.x & 7u) * 8u + ((blockIdx.x >> 3) & 7u);
   return w;
 }
 
@@ -557,40 +516,30 @@ __device__ __forceinline__ void trace_wave_groups(const DevScene& S, const Sourc
   }
 }
 
-#ifdef RTX_DEBUG_TIMES
-#define RTX_DBG_BEGIN const unsigned long long dbg_t0_ = wall_clock64();
-#define RTX_DBG_END { const uint32_t w_ = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); \
-    if ((threadIdx.x & 63) == 0 && w_ < 16384) { g_dbg_times[2 * w_] = dbg_t0_; g_dbg_times[2 * w_ + 1] = wall_clock64(); } }
-#else
-#define RTX_DBG_BEGIN
-#define RTX_DBG_END
-#endif
 
 // Camera rays of a pixel rectangle.  Ray index j = (16x16 pixel block, thread): consecutive
 // indices walk 8x8 pixel sub-tiles, so the 64 rays of a chunk are coherent.  Writes {t, id}.
 template <bool kRefill>
-__global__ __launch_bounds__(kBlock, 8) void k_trace_camera(DevScene S, DevCamera C, uint32_t nblocks, uint32_t grab, uint32_t* counters,
-                                                          uint32_t* ovf, uint2* hits) {
+__global__ __launch_bounds__(kBlock, 8) void k_trace_camera(DevScene S, DevCamera C, uint32_t nblocks, uint32_t grab, uint32_t* ovf,
+                                                          uint2* hits) {
   __shared__ uint32_t lds_stack[(kRefill ? kLdsStack : kLdsStackGroups) * kBlock];
-  RTX_DBG_BEGIN
   CameraSource src; src.C = C;
-  const Work work = make_work(nblocks * (uint32_t)kBlock, grab, counters);
+  const Work work = make_work(nblocks * (uint32_t)kBlock, grab);
   if constexpr (kRefill) {
     __shared__ uint32_t lds_wbuf[(kBlock / 64) * kWbufWords * 64];
     trace_wave(S, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), hits);
   } else {
     trace_wave_groups(S, src, work, make_stack<kLdsStackGroups>(lds_stack, ovf), hits);
   }
-  RTX_DBG_END
 }
 
 // Queued rays: rays[2i] = {o.xyz, aux}, rays[2i+1] = {d1.xyz, aux}; *count * stride rays.
 template <bool kRefill>
 __global__ __launch_bounds__(kBlock, 8) void k_trace_queue(DevScene S, const float4* rays, const uint32_t* count, uint32_t stride,
-                                                         uint32_t grab, uint32_t* counters, uint32_t* ovf, uint2* hits) {
+                                                         uint32_t grab, uint32_t* ovf, uint2* hits) {
   __shared__ uint32_t lds_stack[(kRefill ? kLdsStack : kLdsStackGroups) * kBlock];
   QueueSource src; src.rays = rays;
-  const Work work = make_work(*count * stride, grab, counters);
+  const Work work = make_work(*count * stride, grab);
   if constexpr (kRefill) {
     __shared__ uint32_t lds_wbuf[(kBlock / 64) * kWbufWords * 64];
     trace_wave(S, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), hits);

@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 for wl in soup1M_4k_primary_shadow bunny70k_1080p_primary_shadow hall262k_1080p_reflect3; do
  for sc in refill groups; do
- for wk in ${WORKS:-static}; do
+ for wk in static; do
   RTX_WORK=$wk RTX_SCHED=$sc timeout -k 10 200 python3 -u bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --workload $wl > gpurun_out/ss_${sc}_${wk}_$wl.log 2>&1 || { echo "$wl $sc failed"; tail -5 gpurun_out/ss_${sc}_${wk}_$wl.log; exit 1; }
   python3 - <<PY
 import json
