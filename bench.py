@@ -264,6 +264,18 @@ def roofline(args, wl, scene, info, ms, rays):
     res.update({"kernel": name, "achieved": nbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0,
                 "algorithmic_bytes_per_launch": nbytes / launches, "avg_launch_ms": kms / launches})
     res["frac"] = res["achieved"] / HBM_PEAK_GBS
+    # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this
+    # process, so the figure comes from the committed rocprofv3 --pmc passes of this same
+    # command (profiles/r01_traffic.json, corrected as MI355X_MICROARCH.md prescribes).
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            tr = json.load(f).get(args.workload, {})
+        key = "k_trace_camera" if name == "k_trace_camera" else "k_trace_queue"
+        if key in tr:
+            res["traffic"] = tr[key]["hbm_bytes_per_launch"]
+            res["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits included)"
+    except (OSError, ValueError):
+        pass
     return res
 
 

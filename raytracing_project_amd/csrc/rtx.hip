@@ -92,6 +92,7 @@ struct rtx_scene {
   DevBuf d_nodes, d_tris, d_tri_face, d_face_nm, d_spheres, d_sph_mat, d_mats, d_lights;
   DevBuf d_slights, d_leafboxes, d_leaf_faces, d_face_pos;
   // workspace
+  DevBuf w_cam_tab;                  // per-call camera tables (k_camera_tables)
   DevBuf w_stack_ovf;                // global overflow columns of the per-lane traversal stacks
   DevBuf w_rays[2], w_hits[2], w_parents, w_shadow_rays, w_shadow_hits, w_gi_rays, w_gi_hits, w_counters, w_io[6];
   EventPool events;
@@ -132,7 +133,7 @@ static void release_device(rtx_scene* s) {
   if (s->device >= 0) (void)hipSetDevice(s->device);
   DevBuf* bufs[] = {&s->d_nodes, &s->d_tris, &s->d_tri_face, &s->d_face_nm, &s->d_spheres, &s->d_sph_mat, &s->d_mats,
                     &s->d_lights, &s->d_slights, &s->d_leafboxes, &s->d_leaf_faces, &s->d_face_pos, &s->w_gi_rays,
-                    &s->w_gi_hits, &s->w_stack_ovf, &s->w_rays[0], &s->w_rays[1], &s->w_hits[0], &s->w_hits[1], &s->w_parents,
+                    &s->w_gi_hits, &s->w_stack_ovf, &s->w_cam_tab, &s->w_rays[0], &s->w_rays[1], &s->w_hits[0], &s->w_hits[1], &s->w_parents,
                     &s->w_shadow_rays, &s->w_shadow_hits, &s->w_counters, &s->w_io[0], &s->w_io[1], &s->w_io[2],
                     &s->w_io[3], &s->w_io[4], &s->w_io[5]};
   for (DevBuf* b : bufs) b->release();
@@ -693,7 +694,7 @@ static int make_camera(const rtx_camera* cam, rtx_rect r, DevCamera* C) {
   C->scale = scale;
   C->sub[0] = cam->subpixel[0]; C->sub[1] = cam->subpixel[1];
   C->x0 = r.x0; C->y0 = r.y0; C->w = r.x1 - r.x0; C->h = r.y1 - r.y0;
-  C->ts = 0; C->part = 0; C->nparts = 1; C->tiles_x = 0; C->ntiles_local = 0; C->pad_ = 0;
+  C->ts = 0; C->part = 0; C->nparts = 1; C->tiles_x = 0; C->ntiles_local = 0; C->pad_ = 0; C->tab = nullptr;
   return RTX_OK;
 }
 
@@ -853,7 +854,10 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
 static int render_impl(rtx_scene* s, const DevCamera& C, uint32_t npix, uint32_t tiles, const rtx_options* opt,
                        float* rgb, float* t, int32_t* face) {
   stats_begin(s);
+  if (int rc = s->w_cam_tab.ensure((size_t)(C.w + C.h) * 4)) return rc;
   Primary pr; pr.camera = true; pr.C = C; pr.n0 = npix; pr.tiles = tiles; pr.bounce0 = 0;
+  pr.C.tab = s->w_cam_tab.as<float>();
+  hipLaunchKernelGGL(k_camera_tables, dim3((uint32_t)(C.w + C.h + 255) / 256), dim3(256), 0, s->stream, pr.C, s->w_cam_tab.as<float>());
   if (int rc = run_pipeline(s, pr, opt, rgb, t, face)) return rc;
   uint64_t live = npix;
   if (C.ts) {   // partial edge tiles: count only slots that are pixels of the rectangle

@@ -67,6 +67,7 @@ struct DevCamera {
   // row-major rectangle.
   int ts, part, nparts, tiles_x;
   uint32_t ntiles_local, pad_;
+  const float* tab;    // nx of the w columns, then ny of the h rows (k_camera_tables)
 };
 
 
@@ -186,13 +187,26 @@ struct Stack {
 
 // ---------------------------------------------------------------- camera rays
 // Camera::screenToWorld + Ray ctor (tucano/camera.hpp:155-173, src/flyscene.cpp:463-465)
-__device__ __forceinline__ void camera_ray(const DevCamera& C, int x, int y, V3* o, V3* d1) {
-  const float rx = (float)x + C.sub[0], ry = (float)y + C.sub[1];
-  float nx = (float)(2.0 * (double)(rx - C.vp[0]) / (double)C.vp[2] - 1.0);
-  float ny = (float)(1.0 - 2.0 * (double)(ry - C.vp[1]) / (double)C.vp[3]);
+// The two screen coordinates of Camera::screenToWorld for raster position (rx, ry): the
+// reference evaluates them in double and rounds to float before the aspect / fov scaling.
+__device__ __forceinline__ float camera_nx(const DevCamera& C, float rx) {
+  return (float)(2.0 * (double)(rx - C.vp[0]) / (double)C.vp[2] - 1.0) * C.aspect_scale;
+}
+__device__ __forceinline__ float camera_ny(const DevCamera& C, float ry) {
+  return (float)(1.0 - 2.0 * (double)(ry - C.vp[1]) / (double)C.vp[3]) * C.scale;
+}
+// nx depends on the column only and ny on the row only: k_camera_tables evaluates them once
+// per render call (w + h values), which keeps the fp64 divisions and their registers out of
+// the traversal kernels.
+__global__ void k_camera_tables(DevCamera C, float* tab) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i < C.w) tab[i] = camera_nx(C, (float)(C.x0 + i) + C.sub[0]);
+  else if (i < C.w + C.h) tab[i] = camera_ny(C, (float)(C.y0 + (i - C.w)) + C.sub[1]);
+}
+// Ray of pixel (lx, ly) of the rectangle (relative coordinates).
+__device__ __forceinline__ void camera_ray(const DevCamera& C, int lx, int ly, V3* o, V3* d1) {
+  const float nx = C.tab[lx], ny = C.tab[C.w + ly];
   const float nz = -1.0f;
-  nx *= C.aspect_scale;
-  ny *= C.scale;
   V3 w;
   w.x = ((C.inv34[0] * nx + C.inv34[1] * ny) + C.inv34[2] * nz) + C.inv34[3] * 1.0f;
   w.y = ((C.inv34[4] * nx + C.inv34[5] * ny) + C.inv34[6] * nz) + C.inv34[7] * 1.0f;
@@ -328,7 +342,7 @@ struct CameraSource {
   __device__ __forceinline__ bool get(uint32_t j, V3* o, V3* d1, uint32_t* slot) const {
     int lx, ly;
     if (!block_slot(C, j / kBlock, j % kBlock, slot, &lx, &ly)) return false;
-    camera_ray(C, C.x0 + lx, C.y0 + ly, o, d1);
+    camera_ray(C, lx, ly, o, d1);
     return true;
   }
 };
@@ -580,11 +594,8 @@ __global__ void k_ref_box(const float* o, const float* d, uint32_t n, float lx, 
 __global__ void k_camera_points(DevCamera C, const float* ij, uint32_t n, float* world) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float nx = (float)(2.0 * (double)(ij[2 * i] - C.vp[0]) / (double)C.vp[2] - 1.0);
-  float ny = (float)(1.0 - 2.0 * (double)(ij[2 * i + 1] - C.vp[1]) / (double)C.vp[3]);
+  const float nx = camera_nx(C, ij[2 * i]), ny = camera_ny(C, ij[2 * i + 1]);
   const float nz = -1.0f;
-  nx *= C.aspect_scale;
-  ny *= C.scale;
   world[3 * i] = ((C.inv34[0] * nx + C.inv34[1] * ny) + C.inv34[2] * nz) + C.inv34[3] * 1.0f;
   world[3 * i + 1] = ((C.inv34[4] * nx + C.inv34[5] * ny) + C.inv34[6] * nz) + C.inv34[7] * 1.0f;
   world[3 * i + 2] = ((C.inv34[8] * nx + C.inv34[9] * ny) + C.inv34[10] * nz) + C.inv34[11] * 1.0f;
@@ -659,7 +670,7 @@ __device__ __forceinline__ RayRec load_node(const PipeArgs& A, uint32_t i) {
   if (A.from_camera) {
     int x, y;
     r.valid = slot_pixel(A.C, i, &x, &y);
-    camera_ray(A.C, A.C.x0 + x, A.C.y0 + y, &r.o, &r.d1);
+    camera_ray(A.C, x, y, &r.o, &r.d1);
     r.pixel = i; r.thr = 1.0f; r.inside = false;
     return r;
   }
