@@ -426,7 +426,20 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   std::vector<PackedGroup> dnodes;
   pack_groups(s->bvh.quads, &dnodes);
   if (int rc = upload(s->d_nodes, dnodes, s->stream)) return rc;
-  if (int rc = upload(s->d_tris, tri_leaf, s->stream)) return rc;
+  // Device order of the triangle record: {n, D} {v0, vv} {u, uu} {v, uv}, so that the plane
+  // stage of the test (most triangles stop there) needs one 16-byte load instead of two; the
+  // exported layout of rtx_scene_get_tris stays {v0, D} {u, uu} {v, uv} {n, vv}.
+  {
+    std::vector<float4> dtris(tri_leaf.size());
+    for (size_t k = 0; k + 3 < tri_leaf.size(); k += 4) {
+      const float4 a = tri_leaf[k], u = tri_leaf[k + 1], v = tri_leaf[k + 2], n = tri_leaf[k + 3];
+      dtris[k] = make_float4(n.x, n.y, n.z, a.w);
+      dtris[k + 1] = make_float4(a.x, a.y, a.z, n.w);
+      dtris[k + 2] = u;
+      dtris[k + 3] = v;
+    }
+    if (int rc = upload(s->d_tris, dtris, s->stream)) return rc;
+  }
   if (int rc = upload(s->d_tri_face, tri_face, s->stream)) return rc;
   if (int rc = upload(s->d_face_nm, face_nm, s->stream)) return rc;
   if (int rc = upload(s->d_spheres, ds, s->stream)) return rc;

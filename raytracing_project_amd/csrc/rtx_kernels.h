@@ -34,7 +34,7 @@ static_assert(sizeof(DevMat) == 64, "material record is 64 bytes");
 
 struct DevScene {
   const uint4* nodes;      // 4 x uint4 per 64-byte packed group of 4 sibling nodes (PackedGroup, bvh_build.h)
-  const float4* tris;      // 4 x float4 per leaf-ordered triangle: {v0,D} {u,uu} {v,uv} {n,vv}
+  const float4* tris;      // 4 x float4 per leaf-ordered triangle: {n,D} {v0,vv} {u,uu} {v,uv}
   const int* tri_face;     // leaf order -> mesh face id
   const float4* face_nm;   // per mesh face: {query normal xyz, material id bits}
   const float4* spheres;   // {center xyz, radius}
@@ -126,12 +126,11 @@ __device__ __forceinline__ float cull_inv(float d) {
 // Updates `best` with the reference's reduction: strict < over faces in mesh order, i.e. the
 // lexicographic min of (t, face); a sphere at the same t keeps winning (src/flyscene.cpp:569).
 __device__ __forceinline__ void test_triangle(const DevScene& S, uint32_t k, V3 o, V3 d, Hit* best) {
-  const float4 q3 = S.tris[4 * k + 3];             // n, vv
-  const float4 q0 = S.tris[4 * k];                 // v0, D
-  const V3 n = v3(q3.x, q3.y, q3.z);
+  const float4 qn = S.tris[4 * k];                 // n, D
+  const V3 n = v3(qn.x, qn.y, qn.z);
   const float den = dot(n, d);
   if (den == 0.0f) return;
-  const float num = q0.w - dot(o, n);
+  const float num = qn.w - dot(o, n);
   // Cheap rejection first (hardware reciprocal, 1 ulp): a quotient clearly outside
   // [precision, best] cannot pass the exact comparison below (margin 1e-5 >> 2^-22).
   // (Only for |den| in the normal range, where the reciprocal is that accurate.)
@@ -139,12 +138,13 @@ __device__ __forceinline__ void test_triangle(const DevScene& S, uint32_t k, V3 
   if (fabsf(den) >= 1e-30f && !(tq >= kPrecision * 0.99999f && tq <= best->t * 1.00001f)) return;
   const float t = num / den;
   if (!(t >= kPrecision && t <= best->t)) return;
-  const float4 q1 = S.tris[4 * k + 1];             // u, uu
-  const float4 q2 = S.tris[4 * k + 2];             // v, uv
+  const float4 q0 = S.tris[4 * k + 1];             // v0, vv
+  const float4 q1 = S.tris[4 * k + 2];             // u, uu
+  const float4 q2 = S.tris[4 * k + 3];             // v, uv
   const V3 P = point_on_ray(o, d, t);
   const V3 w = P - v3(q0.x, q0.y, q0.z);
   const float wu = dot(w, v3(q1.x, q1.y, q1.z)), wv = dot(w, v3(q2.x, q2.y, q2.z));
-  const float uu = q1.w, uv = q2.w, vv = q3.w;
+  const float uu = q1.w, uv = q2.w, vv = q0.w;
   const float denom = uu * vv - uv * uv;
   const float s1 = vv * wu - uv * wv;
   const float t1 = uu * wv - uv * wu;
