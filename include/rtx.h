@@ -133,7 +133,10 @@ int rtx_scene_get_info(const rtx_scene*, rtx_scene_info*);
  * holds the root's children.  count > 0: leaf over triangles [ref, ref+count); count == 0: internal,
  * ref = index of its child group; ref == 0xFFFFFFFF: unused slot.  max_depth counts group levels.
  * tri_face: ntris ids in leaf order,
- * the last rtx_scene_info.nwild of them being the triangles outside the hierarchy. */
+ * the last rtx_scene_info.nwild of them being the triangles outside the hierarchy.
+ * (On the device the same groups are held in a 64-byte quantised encoding with outward-rounded
+ * boxes, and the triangle record in the order {n,D}{v0,v.v}{u,u.u}{v,u.v}; these exports are the
+ * fp32 source of both.) */
 int rtx_scene_get_bvh(const rtx_scene*, uint32_t* nodes8, uint32_t* tri_face);
 /* Host copy of the leaf-ordered 64-byte triangle records: ntris x 16 floats
  * {v0.xyz, D}{u.xyz, u.u}{v.xyz, u.v}{n.xyz, v.v} (src/Intersect.cpp:10,26-32 hoisted per triangle). */
