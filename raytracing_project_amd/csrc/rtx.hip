@@ -585,14 +585,15 @@ static int launch_trace_camera(rtx_scene* s, const DevCamera& C, uint32_t tiles,
                        s->w_stack_ovf.as<uint32_t>(), hits);
   return RTX_OK;
 }
-static int launch_trace_queue(rtx_scene* s, const float4* rays, const uint32_t* count, uint32_t stride, uint64_t bound, uint2* hits) {
+static int launch_trace_queue(rtx_scene* s, const float4* rays, const uint32_t* count, uint32_t stride, uint64_t bound, uint2* hits,
+                              bool shadow = false) {
   const uint64_t blocks = (bound * stride + kBlock - 1) / kBlock;
   const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, (uint64_t)trace_grid(s)));
   if (sched_refill(s, false, bound * stride))
-    hipLaunchKernelGGL(k_trace_queue<true>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride, grab_size(),
+    hipLaunchKernelGGL(k_trace_queue<true>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride, shadow ? 1u : 0u, grab_size(),
                        s->w_stack_ovf.as<uint32_t>(), hits);
   else
-    hipLaunchKernelGGL(k_trace_queue<false>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride, grab_size(),
+    hipLaunchKernelGGL(k_trace_queue<false>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride, shadow ? 1u : 0u, grab_size(),
                        s->w_stack_ovf.as<uint32_t>(), hits);
   return RTX_OK;
 }
@@ -672,7 +673,7 @@ extern "C" int rtx_trace_visible(rtx_scene* s, const float* light, const float* 
   hipLaunchKernelGGL(k_make_shadow_rays, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->w_io[0].as<float>(),
                      s->w_io[1].as<float>(), n, s->w_rays[0].as<float4>());
   span_begin(s, true);
-  if (int rc = launch_trace_queue(s, s->w_rays[0].as<float4>(), s->w_counters.as<uint32_t>(), 1u, n, s->w_hits[0].as<uint2>())) return rc;
+  if (int rc = launch_trace_queue(s, s->w_rays[0].as<float4>(), s->w_counters.as<uint32_t>(), 1u, n, s->w_hits[0].as<uint2>(), true)) return rc;
   span_end(s, true);
   hipLaunchKernelGGL(k_visible, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->dev, s->w_io[0].as<float>(),
                      s->w_rays[0].as<float4>(), s->w_hits[0].as<uint2>(), n, s->w_io[2].as<unsigned char>(), s->w_io[3].as<int>());
@@ -834,7 +835,7 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
     if (!shade) break;
     if (opt->shadows && NLS) {
       span_begin(s, true);
-      if (int rc = launch_trace_queue(s, s->w_shadow_rays.as<float4>(), cnt + 4 * g, NLS, bound, s->w_shadow_hits.as<uint2>())) return rc;
+      if (int rc = launch_trace_queue(s, s->w_shadow_rays.as<float4>(), cnt + 4 * g, NLS, bound, s->w_shadow_hits.as<uint2>(), true)) return rc;
       span_end(s, true);
     }
     if (G) {

@@ -337,10 +337,18 @@ __device__ __forceinline__ bool node_step(const DevScene& S, const StackT& stk, 
 
 // Where a wave's rays come from.  get(j): ray j of the launch -> origin, Ray direction d1 and
 // the output slot of its hit record; false where index j holds no ray.
+// Traversal bound of a shadow ray: canSeeLight compares hit distances with |light - P|
+// (src/flyscene.cpp:751-778); anything farther than that (with slack for the ulp-level spread
+// between slab and plane distances, as in kPruneSlack) cannot change its answer.
+__device__ __forceinline__ float shadow_tmax(V3 light, V3 P) { return norm(light - P) * 1.001f; }
+// *tmax: hits beyond it do not matter to the caller (shadow rays: the light's distance with
+// slack; canSeeLight gives the same answer for "closest hit beyond the light" and "no hit"),
+// so traversal starts pruned at tmax; a ray that finds nothing reports t = INFINITY as always.
 struct CameraSource {
   DevCamera C;
-  __device__ __forceinline__ bool get(uint32_t j, V3* o, V3* d1, uint32_t* slot) const {
+  __device__ __forceinline__ bool get(uint32_t j, V3* o, V3* d1, uint32_t* slot, float* tmax) const {
     int lx, ly;
+    *tmax = INFINITY;
     if (!block_slot(C, j / kBlock, j % kBlock, slot, &lx, &ly)) return false;
     camera_ray(C, lx, ly, o, d1);
     return true;
@@ -348,9 +356,11 @@ struct CameraSource {
 };
 struct QueueSource {
   const float4* rays;
-  __device__ __forceinline__ bool get(uint32_t j, V3* o, V3* d1, uint32_t* slot) const {
+  uint32_t bounded;    // rd.w of the records is tmax (shadow queue) rather than a throughput
+  __device__ __forceinline__ bool get(uint32_t j, V3* o, V3* d1, uint32_t* slot, float* tmax) const {
     const float4 ro = rays[2 * (size_t)j], rd = rays[2 * (size_t)j + 1];
     *o = v3(ro.x, ro.y, ro.z); *d1 = v3(rd.x, rd.y, rd.z); *slot = j;
+    *tmax = bounded ? rd.w : INFINITY;
     return true;
   }
 };
@@ -405,7 +415,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& S, const Source& src,
         bool park = false;
         Hit sb; sb.t = INFINITY; sb.id = -1;
         V3 sd = v3(0, 0, 0);
-        if (j < chunk_end && src.get(j, &so, &sd1, &sslot)) {
+        if (j < chunk_end && src.get(j, &so, &sd1, &sslot, &sb.t)) {
           // spheres first, strict < (src/flyscene.cpp:523-532)
           for (uint32_t i = 0; i < S.nspheres; ++i) {
             const float t = ref_sphere_t(so, sd1, S.spheres[i]);
@@ -419,7 +429,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& S, const Source& src,
               park = S.nwild != S.ntris;
             }
           }
-          if (!park) hits[sslot] = make_uint2(__float_as_uint(sb.t), (uint32_t)sb.id);
+          if (!park) hits[sslot] = make_uint2(__float_as_uint(sb.id == -1 ? INFINITY : sb.t), (uint32_t)sb.id);
         }
         const uint64_t pm = __ballot(park);
         if (park) {
@@ -469,7 +479,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& S, const Source& src,
     }
     if (pop) {
       if (sp == 0) {
-        hits[slot] = make_uint2(__float_as_uint(best.t), (uint32_t)best.id);
+        hits[slot] = make_uint2(__float_as_uint(best.id == -1 ? INFINITY : best.t), (uint32_t)best.id);
         cur = kDone;
       } else {
         --sp;
@@ -493,8 +503,8 @@ __device__ __forceinline__ void trace_wave_groups(const DevScene& S, const Sourc
     const uint32_t end = base + work.grab < work.n ? base + work.grab : work.n;
     for (uint32_t j = base + lane; j < end; j += 64) {
       V3 o, d1; uint32_t slot;
-      if (!src.get(j, &o, &d1, &slot)) continue;
-      Hit best; best.t = INFINITY; best.id = -1;
+      Hit best; best.id = -1;
+      if (!src.get(j, &o, &d1, &slot, &best.t)) continue;
       for (uint32_t i = 0; i < S.nspheres; ++i) {
         const float t = ref_sphere_t(o, d1, S.spheres[i]);
         if (t != INFINITY && t < best.t) { best.t = t; best.id = -2 - (int)i; }
@@ -525,7 +535,7 @@ __device__ __forceinline__ void trace_wave_groups(const DevScene& S, const Sourc
           cur = stk.pop(sp);
         }
       }
-      hits[slot] = make_uint2(__float_as_uint(best.t), (uint32_t)best.id);
+      hits[slot] = make_uint2(__float_as_uint(best.id == -1 ? INFINITY : best.t), (uint32_t)best.id);
     }
   }
 }
@@ -550,9 +560,9 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_camera(DevScene S, DevCamer
 // Queued rays: rays[2i] = {o.xyz, aux}, rays[2i+1] = {d1.xyz, aux}; *count * stride rays.
 template <bool kRefill>
 __global__ __launch_bounds__(kBlock, 8) void k_trace_queue(DevScene S, const float4* rays, const uint32_t* count, uint32_t stride,
-                                                         uint32_t grab, uint32_t* ovf, uint2* hits) {
+                                                         uint32_t bounded, uint32_t grab, uint32_t* ovf, uint2* hits) {
   __shared__ uint32_t lds_stack[(kRefill ? kLdsStack : kLdsStackGroups) * kBlock];
-  QueueSource src; src.rays = rays;
+  QueueSource src; src.rays = rays; src.bounded = bounded;
   const Work work = make_work(*count * stride, grab);
   if constexpr (kRefill) {
     __shared__ uint32_t lds_wbuf[(kBlock / 64) * kWbufWords * 64];
@@ -856,7 +866,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(PipeArgs A) {
         const V3 d1s = normalized(normalized(L - sf.P));
         const size_t k = (size_t)slot * NLS + ls;
         A.shadow_rays[2 * k] = make_float4(sf.P.x, sf.P.y, sf.P.z, 0.0f);
-        A.shadow_rays[2 * k + 1] = make_float4(d1s.x, d1s.y, d1s.z, 0.0f);
+        A.shadow_rays[2 * k + 1] = make_float4(d1s.x, d1s.y, d1s.z, shadow_tmax(L, sf.P));
       }
     }
     if (A.gi_rays > 0) {
@@ -1033,7 +1043,7 @@ __global__ void k_make_shadow_rays(const float* light, const float* pos, uint32_
   const V3 L = v3(light[3 * i], light[3 * i + 1], light[3 * i + 2]);
   const V3 d1s = normalized(normalized(L - P));
   rays[2 * (size_t)i] = make_float4(P.x, P.y, P.z, 0.0f);
-  rays[2 * (size_t)i + 1] = make_float4(d1s.x, d1s.y, d1s.z, 0.0f);
+  rays[2 * (size_t)i + 1] = make_float4(d1s.x, d1s.y, d1s.z, shadow_tmax(L, P));
 }
 __global__ void k_visible(DevScene S, const float* light, const float4* rays, const uint2* hits, uint32_t n,
                           unsigned char* visible, int* bmat) {
