@@ -103,7 +103,7 @@ static void* bvh_worker(void* arg) {
         if (!(cur & LEAF_BIT)) {
           const uint32_t* q = j->nodes + 32 * (size_t)cur;      /* 4 sibling slots of 8 words */
           float lim = best_t * PRUNE_SLACK, tn[4];
-          if (ev && ne < j->ev_stride) ev[ne] = 0;
+          if (ev && ne < j->ev_stride) ev[ne] = (uint8_t)(best_id != -1 ? 0x80 : 0);
           ++ne;
           uint32_t en[4];
           for (int k = 0; k < 4; ++k) {
@@ -129,7 +129,7 @@ static void* bvh_worker(void* arg) {
           }
         } else {
           uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
-          if (ev && ne < j->ev_stride) ev[ne] = (uint8_t)cnt;
+          if (ev && ne < j->ev_stride) ev[ne] = (uint8_t)(cnt | (best_id != -1 ? 0x80 : 0));
           ++ne;
           for (uint32_t k = first; k < first + cnt; ++k) { ++tt; tri_test(j, k, o, d, &best_t, &best_id); }
         }
@@ -165,8 +165,8 @@ void ora_bvh_trace(const uint32_t* nodes8, const float* tri16, const int32_t* tr
   for (int i = 0; i < threads; ++i) pthread_join(th[i], NULL);
 }
 
-/* Step log of the same traversal: ev[i*stride + s] = 0 for a node-group step, k > 0 for a leaf
- * step over k triangles; nev[i] = number of steps (may exceed stride: then the log is cut). */
+/* Step log of the same traversal: ev[i*stride + s] & 0x7f = 0 for a node-group step, k > 0 for a leaf
+ * step over k triangles; bit 0x80 = a hit had already been found when the step ran; nev[i] = number of steps (may exceed stride: then the log is cut). */
 void ora_bvh_trace_events(const uint32_t* nodes8, const float* tri16, const int32_t* tri_face, uint32_t ntris, uint32_t nwild,
                           const float* root_lo, const float* root_hi, const float* o, const float* d1, int n,
                           float* t, int32_t* face, uint8_t* ev, uint32_t stride, uint32_t* nev) {

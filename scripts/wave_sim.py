@@ -34,7 +34,7 @@ def events(nodes, tris, order, lo, hi, o, d1, nwild, stride=1024):
                                   f.ctypes.data_as(C.POINTER(C.c_int32)), ev.ctypes.data_as(C.POINTER(C.c_uint8)), stride,
                                   nev.ctypes.data_as(u32))
     assert nev.max() <= stride
-    return ev, nev, t, f
+    return ev & 0x7f, nev, t, f
 
 
 STAT = {}
