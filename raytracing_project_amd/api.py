@@ -53,6 +53,8 @@ SYMBOLS = ["rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_
            "rtx_get_stats", "rtx_scene_build_reference_leafboxes", "rtx_scene_set_leafboxes",
            "rtx_scene_get_leafboxes", "rtx_intersect_box", "rtx_trace_shade", "rtx_camera_points", "rtx_scene_set_flags"]
 
+FLAG_NO_ROOT_GATE, FLAG_SCHED_REFILL, FLAG_SCHED_GROUPS = 1, 2, 4
+
 _lib = None
 
 
@@ -170,6 +172,10 @@ class Scene:
         s = np.zeros((0, 4), np.float32) if sphere_lights is None else \
             np.ascontiguousarray(sphere_lights, np.float32).reshape(-1, 4)
         _check(lib().rtx_scene_set_lights(self.h, fp(p), len(p), fp(s), len(s)))
+
+    def set_flags(self, flags):
+        """RTX_FLAG_* bits (include/rtx.h)."""
+        _check(lib().rtx_scene_set_flags(self.h, flags))
 
     def build(self):
         _check(lib().rtx_scene_build(self.h))

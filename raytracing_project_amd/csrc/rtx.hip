@@ -166,9 +166,10 @@ extern "C" int rtx_scene_set_spheres(rtx_scene* s, const float* cr4, const int32
 
 extern "C" int rtx_scene_set_flags(rtx_scene* s, uint32_t flags) {
   if (!s) return fail(RTX_EINVAL, "null scene");
-  if (flags & ~(uint32_t)RTX_FLAG_NO_ROOT_GATE) return fail(RTX_EINVAL, "unknown flag bits 0x%x", flags);
+  if (flags & ~(uint32_t)(RTX_FLAG_NO_ROOT_GATE | RTX_FLAG_SCHED_REFILL | RTX_FLAG_SCHED_GROUPS)) return fail(RTX_EINVAL, "unknown flag bits 0x%x", flags);
+  if ((flags & RTX_FLAG_SCHED_REFILL) && (flags & RTX_FLAG_SCHED_GROUPS)) return fail(RTX_EINVAL, "pick one scheduler");
+  if ((flags ^ s->flags) & RTX_FLAG_NO_ROOT_GATE) s->committed = false;   // the scheduler bits are host-side only
   s->flags = flags;
-  s->committed = false;
   return RTX_OK;
 }
 
@@ -471,7 +472,7 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   d.slights = s->d_slights.as<float4>(); d.leafboxes = s->d_leafboxes.as<float4>();
   d.leaf_faces = s->d_leaf_faces.as<int>(); d.face_pos = s->d_face_pos.as<int>();
   d.nsl = (uint32_t)(s->slights.size() / 4); d.nleafboxes = (uint32_t)nleaf;
-  d.flags = s->flags; d.pad1 = 0;
+  d.flags = s->flags & RTX_FLAG_NO_ROOT_GATE; d.pad1 = 0;
   d.ntris = ntris; d.nwild = s->nwild; d.nspheres = (uint32_t)(s->spheres.size() / 4); d.nlights = (uint32_t)(s->lights.size() / 3);
   d.nmats = (uint32_t)s->mats.size();
   for (int k = 0; k < 3; ++k) { d.root_lo[k] = s->root_lo[k]; d.root_hi[k] = s->root_hi[k]; }
@@ -568,6 +569,8 @@ static bool sched_refill(const rtx_scene* s, bool camera, uint64_t rays) {
     if (!e) return -1;
     return std::strcmp(e, "refill") == 0 ? 1 : std::strcmp(e, "groups") == 0 ? 0 : -1;
   }();
+  if (s->flags & RTX_FLAG_SCHED_REFILL) return true;
+  if (s->flags & RTX_FLAG_SCHED_GROUPS) return false;
   if (forced >= 0) return forced == 1;
   // Measured: the refilling scheduler wins on queued rays (shadow / bounce rays:
   // incoherent) and on camera rays once a wave has many 64-ray units to draw from (4K frames);
