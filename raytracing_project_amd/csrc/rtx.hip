@@ -98,6 +98,13 @@ struct rtx_scene {
   EventPool events;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_spans, all_spans;
   size_t camera_span = (size_t)-1;   // index into trace_spans of the k_trace_camera launch
+  // Scheduler tuning per launch kind (camera / shadow queue / bounce queue): the first frames of a
+  // scene time both wave schedulers on the real work and keep the faster one (results are
+  // identical either way, tests/test_gpu_parity.py).
+  struct Tune { int calls = 0; int choice = -1; double ms_per_ray[2] = {0, 0}; uint64_t rays_ref = 0; };
+  Tune tune[3];
+  std::vector<int> span_kind;        // kind of each trace span, -1 = not a scheduler-driven launch
+  int cur_kind = -1;
   rtx_stats stats{};
   rtx_scene_info info{};
   int ncu = 256;
@@ -518,12 +525,14 @@ static void span_begin(rtx_scene* s, bool trace) {
   hipEvent_t a = s->events.get(), b = s->events.get();
   (void)hipEventRecord(a, s->stream);
   (trace ? s->trace_spans : s->all_spans).push_back({a, b});
+  if (trace) { s->span_kind.push_back(-1); s->cur_kind = -1; }
 }
 static void span_end(rtx_scene* s, bool trace) {
   (void)hipEventRecord((trace ? s->trace_spans : s->all_spans).back().second, s->stream);
 }
 static void stats_begin(rtx_scene* s) {
   s->events.reset(); s->trace_spans.clear(); s->all_spans.clear(); s->camera_span = (size_t)-1;
+  s->span_kind.clear();
   std::memset(&s->stats, 0, sizeof s->stats);
   span_begin(s, false);
 }
@@ -562,25 +571,66 @@ static uint32_t grab_size() {
   }();
   return g;
 }
-// Scheduler per launch kind: RTX_SCHED = "refill" | "groups" | unset (default below).
-static bool sched_refill(const rtx_scene* s, bool camera, uint64_t rays) {
+// Scheduler per launch kind.  Order of precedence: RTX_FLAG_SCHED_* of the scene, the RTX_SCHED
+// environment variable ("refill" | "groups"), the tuned choice, the heuristic.
+enum { KIND_CAMERA = 0, KIND_SHADOW = 1, KIND_BOUNCE = 2 };
+constexpr uint64_t kTuneMinRays = 200000;   // smaller launches are not worth timing
+static bool sched_heuristic(const rtx_scene* s, int kind, uint64_t rays) {
+  // Measured (DESIGN.md): the refilling scheduler wins on queued rays (shadow / bounce rays:
+  // incoherent) and on camera rays once a wave has many 64-ray units to draw from (4K frames);
+  // group by group wins on the coherent camera rays of smaller frames.
+  if (kind != KIND_CAMERA) return true;
+  return rays >= (uint64_t)trace_grid(s) * (kBlock / 64) * 64 * 8;
+}
+static bool sched_refill(rtx_scene* s, int kind, uint64_t rays) {
   static const int forced = [] {
     const char* e = std::getenv("RTX_SCHED");
     if (!e) return -1;
     return std::strcmp(e, "refill") == 0 ? 1 : std::strcmp(e, "groups") == 0 ? 0 : -1;
   }();
+  if (!s->span_kind.empty()) s->span_kind.back() = kind;
   if (s->flags & RTX_FLAG_SCHED_REFILL) return true;
   if (s->flags & RTX_FLAG_SCHED_GROUPS) return false;
   if (forced >= 0) return forced == 1;
-  // Measured (DESIGN.md): the refilling scheduler wins on queued rays (shadow / bounce rays:
-  // incoherent) and on camera rays once a wave has many 64-ray units to draw from (4K frames);
-  // group by group wins on the coherent camera rays of smaller frames.
-  if (!camera) return true;
-  return rays >= (uint64_t)trace_grid(s) * (kBlock / 64) * 64 * 8;
+  const rtx_scene::Tune& T = s->tune[kind];
+  if (T.choice >= 0) return T.choice == 1;
+  if (T.calls == 1) return true;          // second call of this kind: time the refilling scheduler
+  if (T.calls == 2) return false;         // third: group by group
+  return sched_heuristic(s, kind, rays);  // first (cold caches: not timed)
+}
+// After a render call: per kind, milliseconds per ray of this call's launches -> tuning state.
+static void tune_update(rtx_scene* s) {
+  if ((s->flags & (RTX_FLAG_SCHED_REFILL | RTX_FLAG_SCHED_GROUPS)) || std::getenv("RTX_SCHED")) return;
+  double ms[3] = {0, 0, 0};
+  bool seen[3] = {false, false, false};
+  for (size_t i = 0; i < s->trace_spans.size() && i < s->span_kind.size(); ++i) {
+    const int k = s->span_kind[i];
+    if (k < 0) continue;
+    float m = 0;
+    (void)hipEventElapsedTime(&m, s->trace_spans[i].first, s->trace_spans[i].second);
+    ms[k] += m; seen[k] = true;
+  }
+  const uint64_t rays[3] = {s->stats.rays_primary, s->stats.rays_shadow, s->stats.rays_reflection + s->stats.rays_refraction};
+  for (int k = 0; k < 3; ++k) {
+    rtx_scene::Tune& T = s->tune[k];
+    if (!seen[k] || rays[k] < kTuneMinRays) continue;
+    if (T.rays_ref && (rays[k] > 2 * T.rays_ref || 2 * rays[k] < T.rays_ref)) T = rtx_scene::Tune();   // another workload: start over
+    if (T.choice >= 0) continue;
+    if (T.calls == 0) T.rays_ref = rays[k];
+    if (T.calls == 1) T.ms_per_ray[1] = ms[k] / (double)rays[k];
+    if (T.calls == 2) {
+      T.ms_per_ray[0] = ms[k] / (double)rays[k];
+      const bool h = sched_heuristic(s, k, rays[k]);
+      // the heuristic's pick stays unless the other one is clearly (3 %) faster
+      const double mine = T.ms_per_ray[h ? 1 : 0], other = T.ms_per_ray[h ? 0 : 1];
+      T.choice = (other < 0.97 * mine) ? (h ? 0 : 1) : (h ? 1 : 0);
+    }
+    ++T.calls;
+  }
 }
 static int launch_trace_camera(rtx_scene* s, const DevCamera& C, uint32_t tiles, uint2* hits) {
   const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(tiles, 1), (uint32_t)trace_grid(s));
-  if (sched_refill(s, true, (uint64_t)tiles * kBlock))
+  if (sched_refill(s, KIND_CAMERA, (uint64_t)tiles * kBlock))
     hipLaunchKernelGGL(k_trace_camera<true>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, C, tiles, grab_size(),
                        s->w_stack_ovf.as<uint32_t>(), hits);
   else
@@ -592,7 +642,7 @@ static int launch_trace_queue(rtx_scene* s, const float4* rays, const uint32_t* 
                               bool shadow = false) {
   const uint64_t blocks = (bound * stride + kBlock - 1) / kBlock;
   const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, (uint64_t)trace_grid(s)));
-  if (sched_refill(s, false, bound * stride))
+  if (sched_refill(s, shadow ? KIND_SHADOW : KIND_BOUNCE, bound * stride))
     hipLaunchKernelGGL(k_trace_queue<true>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride, shadow ? 1u : 0u, grab_size(),
                        s->w_stack_ovf.as<uint32_t>(), hits);
   else
@@ -888,6 +938,7 @@ static int render_impl(rtx_scene* s, const DevCamera& C, uint32_t npix, uint32_t
     }
   }
   s->stats.rays_primary = live;
+  tune_update(s);
   return RTX_OK;
 }
 
