@@ -480,6 +480,22 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   d.leaf_faces = s->d_leaf_faces.as<int>(); d.face_pos = s->d_face_pos.as<int>();
   d.nsl = (uint32_t)(s->slights.size() / 4); d.nleafboxes = (uint32_t)nleaf;
   d.flags = s->flags & RTX_FLAG_NO_ROOT_GATE; d.pad1 = 0;
+  // Shader's shadowed branch (src/flyscene.cpp:731-743) colours a blocked light with the
+  // *blocker's* Ka, Kd, Ks, Ns, d.  When every face and sphere has an in-range material and all
+  // those records agree in these fields, any blocker gives the same colour and shadow rays may
+  // stop at the first hit before the light.
+  {
+    bool uniform = !s->mats.empty();
+    for (size_t i = 1; uniform && i < s->mats.size(); ++i) {
+      const rtx_material &a = s->mats[0], &b = s->mats[i];
+      uniform = std::memcmp(a.ka, b.ka, 12) == 0 && std::memcmp(a.kd, b.kd, 12) == 0 && std::memcmp(a.ks, b.ks, 12) == 0 &&
+                std::memcmp(&a.ns, &b.ns, 4) == 0 && std::memcmp(&a.d, &b.d, 4) == 0;
+    }
+    const int nm = (int)s->mats.size();
+    for (size_t i = 0; uniform && i < s->tri_mat.size(); ++i) uniform = s->tri_mat[i] >= 0 && s->tri_mat[i] < nm;
+    for (size_t i = 0; uniform && i < s->sph_mat.size(); ++i) uniform = s->sph_mat[i] >= 0 && s->sph_mat[i] < nm;
+    if (uniform) d.flags |= 2u;
+  }
   d.ntris = ntris; d.nwild = s->nwild; d.nspheres = (uint32_t)(s->spheres.size() / 4); d.nlights = (uint32_t)(s->lights.size() / 3);
   d.nmats = (uint32_t)s->mats.size();
   for (int k = 0; k < 3; ++k) { d.root_lo[k] = s->root_lo[k]; d.root_hi[k] = s->root_hi[k]; }
@@ -639,14 +655,14 @@ static int launch_trace_camera(rtx_scene* s, const DevCamera& C, uint32_t tiles,
   return RTX_OK;
 }
 static int launch_trace_queue(rtx_scene* s, const float4* rays, const uint32_t* count, uint32_t stride, uint64_t bound, uint2* hits,
-                              bool shadow = false) {
+                              bool shadow = false, bool any_blocker = false) {
   const uint64_t blocks = (bound * stride + kBlock - 1) / kBlock;
   const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, (uint64_t)trace_grid(s)));
   if (sched_refill(s, shadow ? KIND_SHADOW : KIND_BOUNCE, bound * stride))
-    hipLaunchKernelGGL(k_trace_queue<true>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride, shadow ? 1u : 0u, grab_size(),
+    hipLaunchKernelGGL(k_trace_queue<true>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride, shadow ? (any_blocker ? 3u : 1u) : 0u, grab_size(),
                        s->w_stack_ovf.as<uint32_t>(), hits);
   else
-    hipLaunchKernelGGL(k_trace_queue<false>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride, shadow ? 1u : 0u, grab_size(),
+    hipLaunchKernelGGL(k_trace_queue<false>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride, shadow ? (any_blocker ? 3u : 1u) : 0u, grab_size(),
                        s->w_stack_ovf.as<uint32_t>(), hits);
   return RTX_OK;
 }
@@ -888,7 +904,7 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
     if (!shade) break;
     if (opt->shadows && NLS) {
       span_begin(s, true);
-      if (int rc = launch_trace_queue(s, s->w_shadow_rays.as<float4>(), cnt + 4 * g, NLS, bound, s->w_shadow_hits.as<uint2>(), true)) return rc;
+      if (int rc = launch_trace_queue(s, s->w_shadow_rays.as<float4>(), cnt + 4 * g, NLS, bound, s->w_shadow_hits.as<uint2>(), true, true)) return rc;
       span_end(s, true);
     }
     if (G) {

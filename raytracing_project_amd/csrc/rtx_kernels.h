@@ -48,6 +48,7 @@ struct DevScene {
   uint32_t ntris, nspheres, nlights, nmats;
   uint32_t nsl, nleafboxes;
   uint32_t flags, pad1;           // bit 0: skip the reference's root-box gate (intersectTriangle semantics)
+                                  // bit 1: every material shades a blocked light alike (set at commit)
   float root_lo[3], root_hi[3];   // Box(mesh) of the reference, used as its root gate
   uint32_t root_entry;            // traversal entry of the BVH root
   uint32_t nwild;                 // ill-conditioned triangles [ntris - nwild, ntris): tested by every ray
@@ -353,10 +354,17 @@ struct CameraSource {
     camera_ray(C, lx, ly, o, d1);
     return true;
   }
+  __device__ __forceinline__ bool first_hit_decides() const { return false; }
+  __device__ __forceinline__ float tmax_of(uint32_t) const { return INFINITY; }
 };
 struct QueueSource {
   const float4* rays;
   uint32_t bounded;    // rd.w of the records is tmax (shadow queue) rather than a throughput
+  uint32_t anyhit;     // shadow queue of a scene whose materials all shade a blocked light alike: any
+                       // hit clearly before the light gives canSeeLight's answer *and* colour, so the
+                       // ray stops there instead of looking for the closest one
+  __device__ __forceinline__ bool first_hit_decides() const { return anyhit != 0; }
+  __device__ __forceinline__ float tmax_of(uint32_t slot) const { return rays[2 * (size_t)slot + 1].w; }
   __device__ __forceinline__ bool get(uint32_t j, V3* o, V3* d1, uint32_t* slot, float* tmax) const {
     const float4 ro = rays[2 * (size_t)j], rd = rays[2 * (size_t)j + 1];
     *o = v3(ro.x, ro.y, ro.z); *d1 = v3(rd.x, rd.y, rd.z); *slot = j;
@@ -429,6 +437,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& S, const Source& src,
               park = S.nwild != S.ntris;
             }
           }
+          if (src.first_hit_decides() && sb.id != -1 && sb.t < 0.998f * src.tmax_of(sslot)) park = false;
           if (!park) hits[sslot] = make_uint2(__float_as_uint(sb.id == -1 ? INFINITY : sb.t), (uint32_t)sb.id);
         }
         const uint64_t pm = __ballot(park);
@@ -475,6 +484,8 @@ __device__ __forceinline__ void trace_wave(const DevScene& S, const Source& src,
         const uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
         for (uint32_t k = first; k < first + cnt; ++k) test_triangle(S, k, o, d, &best);
         pop = true;
+        // tmax = 1.001 |light - P|: a hit below 0.998 tmax is before the light whatever the rounding
+        if (src.first_hit_decides() && best.id != -1 && best.t < 0.998f * src.tmax_of(slot)) sp = 0;
       }
     }
     if (pop) {
@@ -518,6 +529,7 @@ __device__ __forceinline__ void trace_wave_groups(const DevScene& S, const Sourc
           walk = S.nwild != S.ntris;
         }
       }
+      if (src.first_hit_decides() && best.id != -1 && best.t < 0.998f * src.tmax_of(slot)) walk = false;
       if (walk) {
         const float ivx = cull_inv(d.x), ivy = cull_inv(d.y), ivz = cull_inv(d.z);
         const float oix = o.x * ivx, oiy = o.y * ivy, oiz = o.z * ivz;
@@ -529,6 +541,7 @@ __device__ __forceinline__ void trace_wave_groups(const DevScene& S, const Sourc
           } else {
             const uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
             for (uint32_t k = first; k < first + cnt; ++k) test_triangle(S, k, o, d, &best);
+            if (src.first_hit_decides() && best.id != -1 && best.t < 0.998f * src.tmax_of(slot)) break;
           }
           if (sp == 0) break;
           --sp;
@@ -562,7 +575,7 @@ template <bool kRefill>
 __global__ __launch_bounds__(kBlock, 8) void k_trace_queue(DevScene S, const float4* rays, const uint32_t* count, uint32_t stride,
                                                          uint32_t bounded, uint32_t grab, uint32_t* ovf, uint2* hits) {
   __shared__ uint32_t lds_stack[(kRefill ? kLdsStack : kLdsStackGroups) * kBlock];
-  QueueSource src; src.rays = rays; src.bounded = bounded;
+  QueueSource src; src.rays = rays; src.bounded = bounded; src.anyhit = ((bounded & 2u) && (S.flags & 2u)) ? 1u : 0u;
   const Work work = make_work(*count * stride, grab);
   if constexpr (kRefill) {
     __shared__ uint32_t lds_wbuf[(kBlock / 64) * kWbufWords * 64];
