@@ -237,8 +237,12 @@ def roofline(args, wl, scene, info, ms, rays):
     o, d1 = oa.camera_rays(ocam, (0, 0, W, H))
     pick = np.arange(0, W * H, stride)
     threads = min(16, os.cpu_count() or 1)
-    t, f, nv, tt = oa.bvh_trace(nodes, tris, order, lo, hi, o[pick], d1[pick], threads=threads, nwild=info.nwild)
+    t, f, nv, tt, gs, tf = oa.bvh_trace(nodes, tris, order, lo, hi, o[pick], d1[pick], threads=threads, nwild=info.nwild,
+                                        layout_counts=True)
     prim_bytes = (32.0 * nv.sum() + 36.0 * tt.sum()) * stride + 8.0 * W * H
+    # what the device layout really has to load: 64-B packed groups, 16 B for a triangle's plane
+    # stage, 48 B more when it goes on to the barycentrics, 8 B result
+    prim_layout_bytes = (64.0 * gs.sum() + 16.0 * tt.sum() + 48.0 * tf.sum()) * stride + 8.0 * W * H
     res = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
            "bytes_model": "32 B/node visited + 36 B/triangle tested + io (8 B/primary, 72 B/queued ray), counts from the CPU "
                           "mirror traversal of the same BVH on every %d-th pixel, scaled" % stride,
@@ -268,6 +272,13 @@ def roofline(args, wl, scene, info, ms, rays):
     res.update({"kernel": name, "achieved": nbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0,
                 "algorithmic_bytes_per_launch": nbytes / launches, "avg_launch_ms": kms / launches})
     res["frac"] = res["achieved"] / HBM_PEAK_GBS
+    if name == "k_trace_camera" and kms > 0:
+        # the same launch priced by the bytes of the device layout instead of SURVEY 8(d)'s model
+        res["layout_bytes_per_launch"] = prim_layout_bytes * spp / launches
+        res["achieved_layout_bytes"] = prim_layout_bytes * spp / (kms * 1e-3) / 1e9
+        res["frac_layout_bytes"] = res["achieved_layout_bytes"] / HBM_PEAK_GBS
+        res["note"] = ("both figures are load demand, not HBM traffic: the scene is cache resident (see traffic), "
+                       "so frac may exceed 1; the kernel's real bound is the L1 return path (DESIGN.md 5)")
     # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this
     # process, so the figure comes from the committed rocprofv3 --pmc passes of this same
     # command (profiles/r01_traffic.json, corrected as MI355X_MICROARCH.md prescribes).

@@ -120,8 +120,9 @@ def lib():
     return _lib
 
 
-def bvh_trace(nodes8, tri16, tri_face, root_lo, root_hi, o, d1, threads=1, nwild=0):
-    """CPU mirror of the GPU traversal over the BVH exported by librtx: (t, face, nodes_visited, tris_tested)."""
+def bvh_trace(nodes8, tri16, tri_face, root_lo, root_hi, o, d1, threads=1, nwild=0, layout_counts=False):
+    """CPU mirror of the GPU traversal over the BVH exported by librtx: (t, face, nodes_visited, tris_tested)
+    and, with layout_counts, also (group_steps, tris_full): 64-byte group fetches and triangle tests past the plane stage."""
     nodes8 = np.ascontiguousarray(nodes8, np.uint32)
     tri16 = np.ascontiguousarray(tri16, np.float32)
     tri_face = np.ascontiguousarray(tri_face, np.int32)
@@ -134,10 +135,15 @@ def bvh_trace(nodes8, tri16, tri_face, root_lo, root_hi, o, d1, threads=1, nwild
     face = np.zeros(n, np.int32)
     nv = np.zeros(n, np.uint32)
     tt = np.zeros(n, np.uint32)
-    lib().ora_bvh_trace(nodes8.ctypes.data_as(C.POINTER(C.c_uint32)), fp(tri16),
-                        tri_face.ctypes.data_as(C.POINTER(C.c_int32)), len(tri_face), nwild, fp(rl), fp(rh), fp(o), fp(d1),
-                        n, threads, fp(t), face.ctypes.data_as(C.POINTER(C.c_int32)),
-                        nv.ctypes.data_as(C.POINTER(C.c_uint32)), tt.ctypes.data_as(C.POINTER(C.c_uint32)))
+    gs = np.zeros(n, np.uint32)
+    tf = np.zeros(n, np.uint32)
+    u32 = C.POINTER(C.c_uint32)
+    lib().ora_bvh_trace2(nodes8.ctypes.data_as(u32), fp(tri16),
+                         tri_face.ctypes.data_as(C.POINTER(C.c_int32)), len(tri_face), nwild, fp(rl), fp(rh), fp(o), fp(d1),
+                         n, threads, fp(t), face.ctypes.data_as(C.POINTER(C.c_int32)),
+                         nv.ctypes.data_as(u32), tt.ctypes.data_as(u32), gs.ctypes.data_as(u32), tf.ctypes.data_as(u32))
+    if layout_counts:
+        return t, face, nv, tt, gs, tf
     return t, face, nv, tt
 
 

@@ -34,6 +34,7 @@ typedef struct {
   const float* o; const float* d1; int n, tid, nthreads;
   float* t; int32_t* face; uint32_t* nodes_visited; uint32_t* tris_tested;
   uint8_t* ev; uint32_t ev_stride; uint32_t* nev;   /* optional step log (wave-scheduling studies) */
+  uint32_t* group_steps; uint32_t* tris_full;       /* optional: 64-byte group fetches, triangle tests that went past the plane stage */
 } bvh_job;
 
 /* reference root gate: Intersect::BoxObject::intersects (src/Intersect.cpp:67-145) */
@@ -60,13 +61,15 @@ static void slab(const uint32_t* node, const float* iv, const float* oi, float* 
 }
 
 /* Intersect::Triangle::intersects on the hoisted record (src/Intersect.cpp:6-46) */
-static void tri_test(const bvh_job* j, uint32_t k, const float* o, const float* d, float* best_t, int* best_id) {
+static int tri_test(const bvh_job* j, uint32_t k, const float* o, const float* d, float* best_t, int* best_id) {
   const float* q = j->tris + 16 * (size_t)k;
   const float* nrm = q + 12;
   float den = dot3f(nrm, d);
+  int full = 0;
   if (den != 0.0f) {
     float t = (q[3] - dot3f(o, nrm)) / den;
     if (t >= 0.001f && t <= *best_t) {
+      full = 1;
       float P[3] = {o[0] + t * d[0], o[1] + t * d[1], o[2] + t * d[2]};
       float w[3] = {P[0] - q[0], P[1] - q[1], P[2] - q[2]};
       float wu = dot3f(w, q + 4), wv = dot3f(w, q + 8);
@@ -80,6 +83,7 @@ static void tri_test(const bvh_job* j, uint32_t k, const float* o, const float* 
       }
     }
   }
+  return full;
 }
 
 static void* bvh_worker(void* arg) {
@@ -90,13 +94,13 @@ static void* bvh_worker(void* arg) {
     float d[3];
     normalize3f(j->d1 + 3 * i, d);
     float best_t = INFINITY; int best_id = -1;
-    uint32_t nv = 0, tt = 0, ne = 0;
+    uint32_t nv = 0, tt = 0, ne = 0, gs = 0, tf = 0;
     uint8_t* ev = j->ev ? j->ev + (size_t)i * j->ev_stride : NULL;
     if (j->ntris && gate(o, d, j->root_lo, j->root_hi) != INFINITY) {
       float iv[3];
       for (int k = 0; k < 3; ++k) { iv[k] = 1.0f / d[k]; if (!(fabsf(iv[k]) <= 1e18f)) iv[k] = copysignf(1e18f, d[k]); }
       float oi[3] = {o[0] * iv[0], o[1] * iv[1], o[2] * iv[2]};
-      for (uint32_t k = j->ntris - j->nwild; k < j->ntris; ++k) { ++tt; tri_test(j, k, o, d, &best_t, &best_id); }
+      for (uint32_t k = j->ntris - j->nwild; k < j->ntris; ++k) { ++tt; tf += (uint32_t)tri_test(j, k, o, d, &best_t, &best_id); }
       uint32_t cur = 0;     /* group 0 = children of the root */
       int sp = 0;
       if (j->nwild < j->ntris) for (;;) {
@@ -104,7 +108,7 @@ static void* bvh_worker(void* arg) {
           const uint32_t* q = j->nodes + 32 * (size_t)cur;      /* 4 sibling slots of 8 words */
           float lim = best_t * PRUNE_SLACK, tn[4];
           if (ev && ne < j->ev_stride) ev[ne] = (uint8_t)(best_id != -1 ? 0x80 : 0);
-          ++ne;
+          ++ne; ++gs;
           uint32_t en[4];
           for (int k = 0; k < 4; ++k) {
             const uint32_t* nd = q + 8 * k;
@@ -131,7 +135,7 @@ static void* bvh_worker(void* arg) {
           uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
           if (ev && ne < j->ev_stride) ev[ne] = (uint8_t)(cnt | (best_id != -1 ? 0x80 : 0));
           ++ne;
-          for (uint32_t k = first; k < first + cnt; ++k) { ++tt; tri_test(j, k, o, d, &best_t, &best_id); }
+          for (uint32_t k = first; k < first + cnt; ++k) { ++tt; tf += (uint32_t)tri_test(j, k, o, d, &best_t, &best_id); }
         }
         if (sp == 0) break;
         cur = stack[--sp];
@@ -141,10 +145,14 @@ static void* bvh_worker(void* arg) {
     if (j->nodes_visited) j->nodes_visited[i] = nv;
     if (j->tris_tested) j->tris_tested[i] = tt;
     if (j->nev) j->nev[i] = ne;
+    if (j->group_steps) j->group_steps[i] = gs;
+    if (j->tris_full) j->tris_full[i] = tf;
   }
   return NULL;
 }
 
+static uint32_t* g_group_steps = NULL;
+static uint32_t* g_tris_full = NULL;
 /* d1 = the direction a Ray object holds (already normalised once); triangles only, no spheres. */
 void ora_bvh_trace(const uint32_t* nodes8, const float* tri16, const int32_t* tri_face, uint32_t ntris, uint32_t nwild,
                    const float* root_lo, const float* root_hi, const float* o, const float* d1, int n, int threads,
@@ -159,10 +167,21 @@ void ora_bvh_trace(const uint32_t* nodes8, const float* tri16, const int32_t* tr
     j->o = o; j->d1 = d1; j->n = n; j->tid = i; j->nthreads = threads; j->t = t; j->face = face;
     j->nodes_visited = nodes_visited; j->tris_tested = tris_tested;
     j->ev = NULL; j->ev_stride = 0; j->nev = NULL;
+    j->group_steps = g_group_steps; j->tris_full = g_tris_full;
   }
   if (threads == 1) { bvh_worker(&jobs[0]); return; }
   for (int i = 0; i < threads; ++i) pthread_create(&th[i], NULL, bvh_worker, &jobs[i]);
   for (int i = 0; i < threads; ++i) pthread_join(th[i], NULL);
+}
+
+/* ora_bvh_trace plus, per ray, the 64-byte groups fetched and the triangle tests that went past
+ * the plane stage (the bytes the device layout really needs; not thread-safe against itself). */
+void ora_bvh_trace2(const uint32_t* nodes8, const float* tri16, const int32_t* tri_face, uint32_t ntris, uint32_t nwild,
+                    const float* root_lo, const float* root_hi, const float* o, const float* d1, int n, int threads,
+                    float* t, int32_t* face, uint32_t* nodes_visited, uint32_t* tris_tested, uint32_t* group_steps, uint32_t* tris_full) {
+  g_group_steps = group_steps; g_tris_full = tris_full;
+  ora_bvh_trace(nodes8, tri16, tri_face, ntris, nwild, root_lo, root_hi, o, d1, n, threads, t, face, nodes_visited, tris_tested);
+  g_group_steps = NULL; g_tris_full = NULL;
 }
 
 /* Step log of the same traversal: ev[i*stride + s] & 0x7f = 0 for a node-group step, k > 0 for a leaf
@@ -174,6 +193,7 @@ void ora_bvh_trace_events(const uint32_t* nodes8, const float* tri16, const int3
   j.nodes = nodes8; j.tris = tri16; j.tri_face = tri_face; j.ntris = ntris; j.nwild = nwild; j.root_lo = root_lo; j.root_hi = root_hi;
   j.o = o; j.d1 = d1; j.n = n; j.tid = 0; j.nthreads = 1; j.t = t; j.face = face; j.nodes_visited = NULL; j.tris_tested = NULL;
   j.ev = ev; j.ev_stride = stride; j.nev = nev;
+  j.group_steps = NULL; j.tris_full = NULL;
   bvh_worker(&j);
 }
 

@@ -14,7 +14,7 @@
 #define RTX_REFILL_MIN 16   // idle lanes of a wave before parked rays are handed out
 #endif
 #ifndef RTX_DEFER_MIN
-#define RTX_DEFER_MIN 16    // lanes at leaves before the triangle tests run (while node work exists)
+#define RTX_DEFER_MIN 24    // lanes at leaves before the triangle tests run (while node work exists)
 #endif
 
 namespace rtx {

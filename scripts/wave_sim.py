@@ -17,7 +17,7 @@ import bench  # noqa: E402
 from oracle import oracle_api as oa  # noqa: E402
 from raytracing_project_amd import api, scenes  # noqa: E402
 
-CN, CL, CT = 70.0, 12.0, 38.0   # VALU instructions: node-group step, leaf step overhead, per triangle
+CN, CL, CT = 64.0, 2.0, 58.0   # L1-return-path cycles: 4 loads per node-group step, ~3.6 per triangle (TD-bound model)
 
 
 def events(nodes, tris, order, lo, hi, o, d1, nwild, stride=1024):
