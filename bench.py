@@ -49,7 +49,10 @@ def build_workload(name, api, scenes):
         return dict(verts=verts, idx=idx, tri_mat=np.zeros(len(idx), np.int32), mats=[m], lights=lights,
                     view=scenes.look_at_view((0, 0, 3), (0, 0, 0)), W=3840, H=2160, opts=(0, 1, 0, 0, 1, 1), spp=16)
     if name == "bunny70k_1080p_primary_shadow":
-        verts, idx = scenes.blob()
+        # BASELINE config 2: the reference's bundled resources/models/bunny.ply (35,947 verts / 69,451
+        # faces), committed flattened as a fixture because /root/reference does not travel
+        z = np.load(os.path.join(ROOT, "tests", "golden", "scene_bunny.npz"))
+        verts, idx = z["verts"], z["idx"]
         lo, hi = verts.min(0), verts.max(0)
         c, r = (lo + hi) / 2, float(np.linalg.norm(hi - lo) / 2)
         m = mk()   # Tucano Mtl() defaults

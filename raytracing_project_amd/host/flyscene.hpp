@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <ctime>
 #include <chrono>
 #include <fstream>
@@ -224,6 +225,85 @@ inline bool loadObjFile(MeshData& mesh, std::vector<Tucano::Material::Mtl>& mtls
       mesh.idx.push_back(groups[g][i]); mesh.idx.push_back(groups[g][i + 1]); mesh.idx.push_back(groups[g][i + 2]);
       mesh.tri_mat.push_back(group_mat[g]);
     }
+  return true;
+}
+// PLY reader (ascii and binary_little_endian 1.0; vertex x/y/z, any other vertex property skipped;
+// face index lists of any integer type, polygons fan-triangulated in file order).  The reference's
+// src/ never loads a PLY, but BASELINE config 2 is its bundled resources/models/bunny.ply
+// (SURVEY.md 8(f) rank 1); faces come out in file order, which is what Tucano's face order is
+// for an OBJ without groups.  All faces get material -1 (the default Mtl).
+inline bool loadPlyFile(MeshData& mesh, const std::string& filename) {
+  std::ifstream in(filename.c_str(), std::ios::binary);
+  if (!in) { std::cerr << "Cannot open " << filename << std::endl; return false; }
+  struct Prop { std::string name, type, count_type, item_type; bool list = false; };
+  struct Elem { std::string name; size_t count = 0; std::vector<Prop> props; };
+  std::vector<Elem> elems;
+  bool binary = false, header_ok = false;
+  std::string line;
+  if (!std::getline(in, line) || line.compare(0, 3, "ply") != 0) { std::cerr << filename << ": not a PLY file" << std::endl; return false; }
+  while (std::getline(in, line)) {
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    std::istringstream ls(line);
+    std::string key; ls >> key;
+    if (key == "format") { std::string f; ls >> f; if (f == "binary_little_endian") binary = true; else if (f != "ascii") { std::cerr << filename << ": unsupported PLY format " << f << std::endl; return false; } }
+    else if (key == "element") { Elem e; ls >> e.name >> e.count; elems.push_back(e); }
+    else if (key == "property" && !elems.empty()) {
+      Prop p; std::string t; ls >> t;
+      if (t == "list") { p.list = true; ls >> p.count_type >> p.item_type >> p.name; } else { p.type = t; ls >> p.name; }
+      elems.back().props.push_back(p);
+    } else if (key == "end_header") { header_ok = true; break; }
+  }
+  if (!header_ok) { std::cerr << filename << ": truncated PLY header" << std::endl; return false; }
+  auto size_of = [](const std::string& t) -> int {
+    if (t == "char" || t == "uchar" || t == "int8" || t == "uint8") return 1;
+    if (t == "short" || t == "ushort" || t == "int16" || t == "uint16") return 2;
+    if (t == "int" || t == "uint" || t == "float" || t == "int32" || t == "uint32" || t == "float32") return 4;
+    if (t == "double" || t == "float64") return 8;
+    return 0;
+  };
+  auto read_number = [&](const std::string& t, double* out) -> bool {
+    if (!binary) { return (bool)(in >> *out); }
+    unsigned char b[8];
+    const int n = size_of(t);
+    if (n == 0 || !in.read((char*)b, n)) return false;
+    if (t == "float" || t == "float32") { float f; std::memcpy(&f, b, 4); *out = f; }
+    else if (t == "double" || t == "float64") { double d; std::memcpy(&d, b, 8); *out = d; }
+    else if (t == "char" || t == "int8") *out = (signed char)b[0];
+    else if (t == "uchar" || t == "uint8") *out = b[0];
+    else if (t == "short" || t == "int16") { int16_t v; std::memcpy(&v, b, 2); *out = v; }
+    else if (t == "ushort" || t == "uint16") { uint16_t v; std::memcpy(&v, b, 2); *out = v; }
+    else if (t == "int" || t == "int32") { int32_t v; std::memcpy(&v, b, 4); *out = v; }
+    else { uint32_t v; std::memcpy(&v, b, 4); *out = v; }
+    return true;
+  };
+  const size_t vert0 = mesh.verts.size() / 3;
+  for (const Elem& e : elems) {
+    for (size_t k = 0; k < e.count; ++k) {
+      float xyz[3] = {0, 0, 0};
+      for (const Prop& p : e.props) {
+        if (!p.list) {
+          double v;
+          if (!read_number(p.type, &v)) { std::cerr << filename << ": truncated PLY body" << std::endl; return false; }
+          if (e.name == "vertex") { if (p.name == "x") xyz[0] = (float)v; else if (p.name == "y") xyz[1] = (float)v; else if (p.name == "z") xyz[2] = (float)v; }
+        } else {
+          double n;
+          if (!read_number(p.count_type, &n)) { std::cerr << filename << ": truncated PLY body" << std::endl; return false; }
+          std::vector<uint32_t> ids((size_t)n);
+          for (size_t i = 0; i < ids.size(); ++i) {
+            double v;
+            if (!read_number(p.item_type, &v)) { std::cerr << filename << ": truncated PLY body" << std::endl; return false; }
+            ids[i] = (uint32_t)((int64_t)v + (int64_t)vert0);
+          }
+          if (e.name == "face" && (p.name == "vertex_indices" || p.name == "vertex_index"))
+            for (size_t i = 1; i + 1 < ids.size(); ++i) {
+              mesh.idx.push_back(ids[0]); mesh.idx.push_back(ids[i]); mesh.idx.push_back(ids[i + 1]);
+              mesh.tri_mat.push_back(-1);
+            }
+        }
+      }
+      if (e.name == "vertex") { mesh.verts.push_back(xyz[0]); mesh.verts.push_back(xyz[1]); mesh.verts.push_back(xyz[2]); }
+    }
+  }
   return true;
 }
 inline void writePPMImage(const std::string& filename, const std::vector<std::vector<Vector3f>>& data) {

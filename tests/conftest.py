@@ -47,7 +47,7 @@ def rtx_materials(arr):
                               illum=int(m[12])) for m in arr]
 
 
-SCENES = ["planeobj", "cube", "twoObjects", "test", "plane", "spheres", "toy", "dodgeColorTest"]
+SCENES = ["planeobj", "cube", "twoObjects", "test", "plane", "spheres", "toy", "dodgeColorTest", "bunny"]
 CAMS = ["default", "oblique", "top"]
 
 

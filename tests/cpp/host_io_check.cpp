@@ -1,0 +1,62 @@
+// Host-side I/O of the C++ facade, driven by tests/test_host_io.py (no GPU involved):
+//   host_io_check obj <file.obj> <out.bin>   load with rtxhost::loadObjFile, dump the flattened arrays
+//   host_io_check ply <file.ply> <out.bin>   same for rtxhost::loadPlyFile
+//   host_io_check ppm <in.bin> <out.ppm>     in.bin = int32 W, int32 H, float rgb[H][W][3] -> writePPMImage
+// Dump layout: int32 nverts, ntris, nmats; float verts[nverts*3]; uint32 idx[ntris*3]; int32 tri_mat[ntris];
+// per material: float ka[3], kd[3], ks[3], ns, ni, d; int32 illum.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../raytracing_project_amd/host/flyscene.hpp"
+
+using namespace rtxhost;
+
+static int dump(const MeshData& m, const std::vector<Tucano::Material::Mtl>& mats, const char* path) {
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return 2;
+  const int32_t hdr[3] = {(int32_t)(m.verts.size() / 3), (int32_t)m.tri_mat.size(), (int32_t)mats.size()};
+  std::fwrite(hdr, 4, 3, f);
+  std::fwrite(m.verts.data(), 4, m.verts.size(), f);
+  std::fwrite(m.idx.data(), 4, m.idx.size(), f);
+  std::fwrite(m.tri_mat.data(), 4, m.tri_mat.size(), f);
+  for (const auto& mt : mats) {
+    const rtx_material r = mt.raw();
+    std::fwrite(r.ka, 4, 3, f); std::fwrite(r.kd, 4, 3, f); std::fwrite(r.ks, 4, 3, f);
+    std::fwrite(&r.ns, 4, 1, f); std::fwrite(&r.ni, 4, 1, f); std::fwrite(&r.d, 4, 1, f); std::fwrite(&r.illum, 4, 1, f);
+  }
+  std::fclose(f);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc != 4) { std::fprintf(stderr, "usage: host_io_check obj|ply|ppm <in> <out>\n"); return 64; }
+  const std::string mode = argv[1];
+  if (mode == "obj" || mode == "ply") {
+    MeshData m;
+    std::vector<Tucano::Material::Mtl> mats;
+    const bool ok = mode == "obj" ? loadObjFile(m, mats, argv[2]) : loadPlyFile(m, argv[2]);
+    if (!ok) return 1;
+    return dump(m, mats, argv[3]);
+  }
+  if (mode == "ppm") {
+    FILE* f = std::fopen(argv[2], "rb");
+    if (!f) return 2;
+    int32_t wh[2];
+    if (std::fread(wh, 4, 2, f) != 2) return 2;
+    std::vector<float> px((size_t)wh[0] * wh[1] * 3);
+    if (std::fread(px.data(), 4, px.size(), f) != px.size()) return 2;
+    std::fclose(f);
+    // the reference's framebuffer is pixel_data[i][j] with i = column (src/flyscene.cpp:411-415)
+    std::vector<std::vector<Vector3f>> data((size_t)wh[0], std::vector<Vector3f>((size_t)wh[1]));
+    for (int j = 0; j < wh[1]; ++j)
+      for (int i = 0; i < wh[0]; ++i) {
+        const float* p = &px[((size_t)j * wh[0] + i) * 3];
+        data[i][j] = Vector3f(p[0], p[1], p[2]);
+      }
+    writePPMImage(argv[3], data);
+    return 0;
+  }
+  return 64;
+}

@@ -4,6 +4,7 @@
                    src/Intersect.cpp, src/Ray.h, tucano/camera.hpp compiled in place)
   scene_*.npz      bundled OBJ scenes flattened by the Tucano-order loader restatement
                    (inputs) + closest-hit / shading dumps of the C oracle at 48x48 (outputs)
+  scene_bunny.npz  resources/models/bunny.ply flattened by a numpy PLY reader (inputs) + the same dumps
   survey_observations.json  outputs of the unmodified reference recorded in SURVEY.md 8(c)
 
 Usage: python tests/golden/make_golden.py
@@ -141,6 +142,32 @@ def scene_fixture(name, res=48):
     print(name, len(verts), len(idx), len(mats), "leaves", int(out["leaves"]))
 
 
+def bunny_fixture(res=48):
+    """BASELINE config 2: resources/models/bunny.ply (35,947 verts / 69,451 faces) with the single
+    default material, flattened in file order; 48x48 dumps of the C oracle like the OBJ scenes."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from plyio import np_read_ply
+    verts, idx = np_read_ply(os.path.join(MODELS, "bunny.ply"))
+    tm = np.zeros(len(idx), np.int32)
+    mats = [oa.make_mtl()]
+    out = {"verts": verts, "idx": idx, "tri_mat": tm, "mats": mtl_array(mats), "res": np.int32(res), "leaves": np.int32(-1)}
+    s = oa.Scene(verts, idx, tm, mats)
+    lo, hi = verts.min(0), verts.max(0)
+    ctr, rad = (lo + hi) / 2, float(np.linalg.norm(hi - lo) / 2)
+    s.set_lights([[-1.0, 1.0, 1.0]])                       # as the other scene fixtures (src/flyscene.cpp:48)
+    for cname, cam in CAMERAS.items():
+        eye = ctr + np.array([0, 0, 2 * rad]) if cam is None else ctr + rad * np.asarray(cam[0]) / 1.5
+        view = scenes.look_at_view(eye, ctr if cam is None else ctr + rad * np.asarray(cam[1]))
+        c = oa.make_camera(view, res, res)
+        out["view_" + cname] = view
+        _, t, face = s.render(c, (0, 0, res, res), threads=8, want_rgb=False)
+        out["t_" + cname], out["face_" + cname] = t, face
+        s.set_options(max_bounces=2, reflection=1, refraction=0, gi_rays=0, shadows=1, skip_zero_weight=0)
+        out["rgb_ns_" + cname] = s.render(c, (0, 0, res, res), threads=8, want_hits=False)[0]
+        print("bunny", cname, "hits", int((face >= 0).sum()))
+    np.savez_compressed(os.path.join(HERE, "scene_bunny.npz"), **out)
+
+
 def default_scene_with_spheres(res=48):
     """The reference's real render state: planeobj + 13 spheres (src/flyscene.cpp:452-458)."""
     verts, idx, tm, mats, _ = oa.obj_load(os.path.join(MODELS, "planeobj.obj"))
@@ -180,8 +207,12 @@ def survey_observations():
 
 if __name__ == "__main__":
     oa.build(force=True)
+    if sys.argv[1:] == ["bunny"]:
+        bunny_fixture()
+        sys.exit(0)
     primitives()
     for name in ("planeobj", "cube", "twoObjects", "test", "plane", "spheres", "toy", "dodgeColorTest"):
         scene_fixture(name)
+    bunny_fixture()
     default_scene_with_spheres()
     survey_observations()
