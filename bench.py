@@ -240,8 +240,10 @@ def roofline(args, wl, scene, info, ms, rays):
     o, d1 = oa.camera_rays(ocam, (0, 0, W, H))
     pick = np.arange(0, W * H, stride)
     threads = min(16, os.cpu_count() or 1)
+    t_cpu0 = time.perf_counter()
     t, f, nv, tt, gs, tf = oa.bvh_trace(nodes, tris, order, lo, hi, o[pick], d1[pick], threads=threads, nwild=info.nwild,
                                         layout_counts=True)
+    cpu_bvh_s = time.perf_counter() - t_cpu0
     prim_bytes = (32.0 * nv.sum() + 36.0 * tt.sum()) * stride + 8.0 * W * H
     # what the device layout really has to load: 64-B packed groups, 16 B for a triangle's plane
     # stage, 48 B more when it goes on to the barycentrics, 8 B result
@@ -275,6 +277,12 @@ def roofline(args, wl, scene, info, ms, rays):
     res.update({"kernel": name, "achieved": nbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0,
                 "algorithmic_bytes_per_launch": nbytes / launches, "avg_launch_ms": kms / launches})
     res["frac"] = res["achieved"] / HBM_PEAK_GBS
+    # compulsory floor: the scene and the framebuffer touched once
+    scene_bytes = 64.0 * (info.nnodes / 4.0) + 64.0 * info.ntris + 4.0 * info.ntris
+    res["compulsory_bytes_per_frame"] = scene_bytes + 20.0 * W * H
+    # the same traversal of the same BVH on the host's cores (the "same algorithm on the CPU" figure of SURVEY 8(d))
+    res["cpu_bvh_traversal"] = {"value": len(pick) / cpu_bvh_s / 1e6, "unit": "Mrays/s (primary)", "cores": threads,
+                                "sample": "every %d-th pixel's primary ray, oracle/rt_oracle_bvh.c" % stride}
     if name == "k_trace_camera" and kms > 0:
         # the same launch priced by the bytes of the device layout instead of SURVEY 8(d)'s model
         res["layout_bytes_per_launch"] = prim_layout_bytes * spp / launches
