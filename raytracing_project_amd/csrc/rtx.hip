@@ -646,8 +646,9 @@ static void tune_update(rtx_scene* s) {
 }
 static int launch_trace_camera(rtx_scene* s, const DevCamera& C, uint32_t tiles, uint2* hits) {
   const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(tiles, 1), (uint32_t)trace_grid(s));
+  const uint32_t grid_r = std::min<uint32_t>(grid, (uint32_t)s->ncu * RTX_BLOCKS_REFILL);
   if (sched_refill(s, KIND_CAMERA, (uint64_t)tiles * kBlock))
-    hipLaunchKernelGGL(k_trace_camera<true>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, C, tiles, grab_size(),
+    hipLaunchKernelGGL(k_trace_camera<true>, dim3(grid_r), dim3(kBlock), 0, s->stream, s->dev, C, tiles, grab_size(),
                        s->w_stack_ovf.as<uint32_t>(), hits);
   else
     hipLaunchKernelGGL(k_trace_camera<false>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, C, tiles, grab_size(),
@@ -658,8 +659,9 @@ static int launch_trace_queue(rtx_scene* s, const float4* rays, const uint32_t* 
                               bool shadow = false, bool any_blocker = false) {
   const uint64_t blocks = (bound * stride + kBlock - 1) / kBlock;
   const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, (uint64_t)trace_grid(s)));
+  const uint32_t grid_r = std::min<uint32_t>(grid, (uint32_t)s->ncu * RTX_BLOCKS_REFILL);
   if (sched_refill(s, shadow ? KIND_SHADOW : KIND_BOUNCE, bound * stride))
-    hipLaunchKernelGGL(k_trace_queue<true>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride, shadow ? (any_blocker ? 3u : 1u) : 0u, grab_size(),
+    hipLaunchKernelGGL(k_trace_queue<true>, dim3(grid_r), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride, shadow ? (any_blocker ? 3u : 1u) : 0u, grab_size(),
                        s->w_stack_ovf.as<uint32_t>(), hits);
   else
     hipLaunchKernelGGL(k_trace_queue<false>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride, shadow ? (any_blocker ? 3u : 1u) : 0u, grab_size(),

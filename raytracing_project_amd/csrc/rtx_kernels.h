@@ -10,6 +10,11 @@
 
 #include "rtx_math.h"
 
+#ifndef RTX_BLOCKS_REFILL
+#define RTX_BLOCKS_REFILL 7   // resident blocks per CU the refilling kernels are compiled for: 72 VGPRs, no
+                              // spills (at 8 the camera kernel spilled 15 VGPRs and wrote 0.4 GB of scratch per
+                              // launch for the same speed)
+#endif
 #ifndef RTX_REFILL_MIN
 #define RTX_REFILL_MIN 16   // idle lanes of a wave before parked rays are handed out
 #endif
@@ -21,7 +26,7 @@ namespace rtx {
 
 constexpr int kBlock = 256;          // 4 waves of 64
 constexpr int kStackDepth = 48;      // per-lane traversal stack entries in total (<= 3 per level of 4-node groups, <= 15 levels)
-constexpr int kLdsStack = 10;        // the first entries live in LDS (10 KB + 9 KB of parked rays per block -> 8 waves/SIMD);
+constexpr int kLdsStack = 13;        // the first entries live in LDS (13 KB + 9 KB of parked rays per block -> 7 blocks per CU);
 constexpr int kLdsStackGroups = 16;  // same for the group-by-group scheduler, which parks nothing
                                      // deeper ones (rare) spill to a per-thread global column
 constexpr uint32_t kLeafBit = 0x80000000u;
@@ -557,7 +562,7 @@ __device__ __forceinline__ void trace_wave_groups(const DevScene& S, const Sourc
 // Camera rays of a pixel rectangle.  Ray index j = (16x16 pixel block, thread): consecutive
 // indices walk 8x8 pixel sub-tiles, so the 64 rays of a chunk are coherent.  Writes {t, id}.
 template <bool kRefill>
-__global__ __launch_bounds__(kBlock, 8) void k_trace_camera(DevScene S, DevCamera C, uint32_t nblocks, uint32_t grab, uint32_t* ovf,
+__global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_trace_camera(DevScene S, DevCamera C, uint32_t nblocks, uint32_t grab, uint32_t* ovf,
                                                           uint2* hits) {
   __shared__ uint32_t lds_stack[(kRefill ? kLdsStack : kLdsStackGroups) * kBlock];
   CameraSource src; src.C = C;
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_camera(DevScene S, DevCamer
 
 // Queued rays: rays[2i] = {o.xyz, aux}, rays[2i+1] = {d1.xyz, aux}; *count * stride rays.
 template <bool kRefill>
-__global__ __launch_bounds__(kBlock, 8) void k_trace_queue(DevScene S, const float4* rays, const uint32_t* count, uint32_t stride,
+__global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_trace_queue(DevScene S, const float4* rays, const uint32_t* count, uint32_t stride,
                                                          uint32_t bounded, uint32_t grab, uint32_t* ovf, uint2* hits) {
   __shared__ uint32_t lds_stack[(kRefill ? kLdsStack : kLdsStackGroups) * kBlock];
   QueueSource src; src.rays = rays; src.bounded = bounded; src.anyhit = ((bounded & 2u) && (S.flags & 2u)) ? 1u : 0u;
