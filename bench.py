@@ -129,19 +129,37 @@ def main():
     rect = (0, 0, W, H)
     kmax = tiles.max_local_tiles(W, H, TILE, world)
     npix_local = kmax * TILE * TILE
-    rgb = torch.zeros((npix_local, 3), dtype=torch.float32, device=dev)
-    acc = torch.zeros_like(rgb) if len(cams) > 1 else None
-    face = torch.full((npix_local, 1), -1, dtype=torch.int32, device=dev)
+    # Two sets of output buffers: the render of frame k+1 (librtx's own stream) overlaps the gather
+    # and reassembly of frame k (torch's streams); a set is reused only after the torch work that
+    # read it has finished (event per set).
+    NSETS = 2
+    sets = []
+    for _ in range(NSETS):
+        b = {"rgb": torch.zeros((npix_local, 3), dtype=torch.float32, device=dev),
+             "face": torch.full((npix_local, 1), -1, dtype=torch.int32, device=dev),
+             "free": torch.cuda.Event()}
+        b["acc"] = torch.zeros_like(b["rgb"]) if len(cams) > 1 else None
+        if world > 1 and rank == 0:
+            b["g_rgb"] = torch.empty((world, npix_local, 3), dtype=torch.float32, device=dev)
+            b["g_face"] = torch.empty((world, npix_local, 1), dtype=torch.int32, device=dev)
+        b["free"].record()
+        sets.append(b)
+    state = {"k": 0}
 
     def frame():
         """One frame: render my tiles (all spp passes), gather to rank 0, assemble."""
+        b = sets[state["k"] % NSETS]
+        state["k"] += 1
+        rgb, face, acc = b["rgb"], b["face"], b["acc"]
         rays = [0, 0, 0]
         ms = [0.0, 0.0, 0.0]
+        b["free"].synchronize()            # torch is done with this set (frame k - 2)
         if acc is not None:
             acc.zero_()
         for cam in cams:
-            # librtx runs on its own HIP stream: torch work touching rgb/face must be done first
-            torch.cuda.current_stream().synchronize()
+            if acc is not None:
+                # librtx runs on its own HIP stream: the accumulation that reads rgb must be done first
+                torch.cuda.current_stream().synchronize()
             scene.render_tiles_dev(cam, opts, rect, TILE, rank, world, rgb.data_ptr(), None, face.data_ptr())
             st = scene.stats()
             rays[0] += st.rays_primary
@@ -153,11 +171,12 @@ def main():
             if acc is not None:
                 acc.add_(rgb)
         out = rgb if acc is None else acc.mul_(1.0 / len(cams))
-        g_rgb = tiles.gather_to_root(out, world, rank, dist)
-        g_face = tiles.gather_to_root(face, world, rank, dist)
+        g_rgb = tiles.gather_to_root(out, world, rank, dist, b.get("g_rgb"))
+        g_face = tiles.gather_to_root(face, world, rank, dist, b.get("g_face"))
         img = None
         if rank == 0:
             img = (tiles.assemble(g_rgb, W, H, TILE, 3), tiles.assemble(g_face, W, H, TILE, 1))
+        b["free"].record()
         return rays, ms, img
 
     def sync():

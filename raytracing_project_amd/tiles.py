@@ -35,10 +35,16 @@ def assemble(parts, width, height, ts, channels):
     return t[:height, :width]
 
 
-def gather_to_root(local, world, rank, dist=None):
-    """local: [kmax*ts*ts, channels] on every rank (same shape).  Returns [world, ...] on rank 0, None elsewhere."""
+def gather_to_root(local, world, rank, dist=None, out=None):
+    """local: [kmax*ts*ts, channels] on every rank (same shape).  Returns [world, ...] on rank 0, None elsewhere.
+    out: optional preallocated [world, ...] tensor on rank 0 (the gather then lands in place: no per-frame
+    allocation, no stacking copy)."""
     if world == 1:
         return local.unsqueeze(0)
-    out = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
-    dist.gather(local, out, dst=0)
-    return torch.stack(out) if rank == 0 else None
+    if rank != 0:
+        dist.gather(local, None, dst=0)
+        return None
+    if out is None:
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    dist.gather(local, [out[i] for i in range(world)], dst=0)
+    return out

@@ -43,9 +43,15 @@ def _worker(rank, world, port, W, H, ts, ret):
     kmax = tiles.max_local_tiles(W, H, ts, world)
     local = fake_render_tiles(W, H, ts, rank, world, kmax)
     parts = tiles.gather_to_root(local, world, rank, dist)
+    # the bench's form: preallocated destination on rank 0, reused across frames
+    pre = torch.full((world,) + tuple(local.shape), -7.0) if rank == 0 else None
+    parts2 = None
+    for _ in range(2):
+        parts2 = tiles.gather_to_root(local, world, rank, dist, pre)
     if rank == 0:
         img = tiles.assemble(parts, W, H, ts, 3).numpy()
-        ret["ok"] = bool(np.array_equal(img, expected(W, H)))
+        img2 = tiles.assemble(parts2, W, H, ts, 3).numpy()
+        ret["ok"] = bool(np.array_equal(img, expected(W, H))) and bool(np.array_equal(img2, expected(W, H))) and parts2 is pre
     dist.barrier()
     dist.destroy_process_group()
 
