@@ -9,6 +9,7 @@
 #include <atomic>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -16,7 +17,11 @@ namespace rtx {
 namespace {
 
 constexpr int kBins = 16;
-constexpr float kTravCost = 1.2f;
+// SAH cost of a split relative to one triangle test.  Measured on the GPU (RTX_TRAV_COST is the tuning
+// hook): against 1.2, 0.6 (leaves of mostly one triangle) gives the soup +7 %, the hall the same, the bunny
+// -8 %; 0.8 gives +4 % / same / same (leaf steps run at the lowest lane utilisation, so small leaves
+// pay on incoherent rays and cost node steps on coherent ones).
+static const float kTravCost = [] { const char* e = std::getenv("RTX_TRAV_COST"); return e ? (float)std::atof(e) : 0.8f; }();
 
 struct Box3 {
   float lo[3], hi[3];
