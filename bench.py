@@ -128,7 +128,8 @@ def main():
     cams = [api.make_camera(wl["view"], W, H, subpixel=o) for o in offsets]
     rect = (0, 0, W, H)
     kmax = tiles.max_local_tiles(W, H, TILE, world)
-    npix_local = kmax * TILE * TILE
+    # one rank owns the whole frame: render it row-major in place, nothing to gather or reassemble
+    npix_local = kmax * TILE * TILE if world > 1 else W * H
     # Two sets of output buffers: the render of frame k+1 (librtx's own stream) overlaps the gather
     # and reassembly of frame k (torch's streams); a set is reused only after the torch work that
     # read it has finished (event per set).
@@ -160,7 +161,10 @@ def main():
             if acc is not None:
                 # librtx runs on its own HIP stream: the accumulation that reads rgb must be done first
                 torch.cuda.current_stream().synchronize()
-            scene.render_tiles_dev(cam, opts, rect, TILE, rank, world, rgb.data_ptr(), None, face.data_ptr())
+            if world > 1:
+                scene.render_tiles_dev(cam, opts, rect, TILE, rank, world, rgb.data_ptr(), None, face.data_ptr())
+            else:
+                scene.render_dev(cam, opts, rect, rgb.data_ptr(), None, face.data_ptr())
             st = scene.stats()
             rays[0] += st.rays_primary
             rays[1] += st.rays_shadow
@@ -171,11 +175,14 @@ def main():
             if acc is not None:
                 acc.add_(rgb)
         out = rgb if acc is None else acc.mul_(1.0 / len(cams))
-        g_rgb = tiles.gather_to_root(out, world, rank, dist, b.get("g_rgb"))
-        g_face = tiles.gather_to_root(face, world, rank, dist, b.get("g_face"))
-        img = None
-        if rank == 0:
-            img = (tiles.assemble(g_rgb, W, H, TILE, 3), tiles.assemble(g_face, W, H, TILE, 1))
+        if world > 1:
+            g_rgb = tiles.gather_to_root(out, world, rank, dist, b.get("g_rgb"))
+            g_face = tiles.gather_to_root(face, world, rank, dist, b.get("g_face"))
+            img = None
+            if rank == 0:
+                img = (tiles.assemble(g_rgb, W, H, TILE, 3), tiles.assemble(g_face, W, H, TILE, 1))
+        else:
+            img = (out.view(H, W, 3), face.view(H, W, 1))
         b["free"].record()
         return rays, ms, img
 
@@ -219,7 +226,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "triangles": int(info.ntris), "bvh_nodes": int(info.nnodes),
                        "image": [W, H], "lights": len(wl["lights"]), "spp": wl["spp"], "max_bounces": wl["opts"][0],
-                       "tile": TILE, "partition": "image tiles round-robin over %d rank(s), scene replicated, gather to rank 0" % world,
+                       "tile": TILE, "partition": ("image tiles round-robin over %d ranks, scene replicated, gather to rank 0" % world) if world > 1
+                       else "one rank renders the whole frame row-major",
                        "rays_per_frame": {"primary": int(agg[0].item() / args.steps), "shadow": int(agg[1].item() / args.steps),
                                           "reflection": int(agg[2].item() / args.steps)},
                        "pixels_hitting_geometry": hits,
