@@ -143,6 +143,12 @@ int rtx_scene_get_info(const rtx_scene*, rtx_scene_info*);
  * boxes, and the triangle record in the order {n,D}{v0,v.v}{u,u.u}{v,u.v}; these exports are the
  * fp32 source of both.) */
 int rtx_scene_get_bvh(const rtx_scene*, uint32_t* nodes8, uint32_t* tri_face);
+/* The same groups in the 64-byte encoding the kernels load: nnodes / 4 x 16 words
+ * {origin.xyz (float), exps, entry[4], lox, loy, loz, hix, hiy, hiz, 0, 0}; plane = origin +
+ * byte * 2^(exp - 127) per axis (byte k of a plane word = child k, byte a of exps = axis a), rounded
+ * outwards; entry = 0x80000000 | count << 28 | first triangle (leaf), child group (internal),
+ * 0xFFFFFFFF (unused).  Inspection only (tests); no counterpart in the reference. */
+int rtx_scene_get_packed_bvh(const rtx_scene*, uint32_t* groups16);
 /* Host copy of the leaf-ordered 64-byte triangle records: ntris x 16 floats
  * {v0.xyz, D}{u.xyz, u.u}{v.xyz, u.v}{n.xyz, v.v} (src/Intersect.cpp:10,26-32 hoisted per triangle). */
 int rtx_scene_get_tris(const rtx_scene*, float* tri16);

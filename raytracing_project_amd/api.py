@@ -51,7 +51,8 @@ SYMBOLS = ["rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_
            "rtx_scene_get_info", "rtx_scene_get_bvh", "rtx_trace_closest", "rtx_trace_closest_dev",
            "rtx_trace_visible", "rtx_render", "rtx_render_dev", "rtx_tiles_count", "rtx_render_tiles_dev",
            "rtx_get_stats", "rtx_scene_build_reference_leafboxes", "rtx_scene_set_leafboxes",
-           "rtx_scene_get_leafboxes", "rtx_intersect_box", "rtx_trace_shade", "rtx_camera_points", "rtx_scene_set_flags"]
+           "rtx_scene_get_leafboxes", "rtx_intersect_box", "rtx_trace_shade", "rtx_camera_points", "rtx_scene_set_flags",
+           "rtx_scene_get_packed_bvh"]
 
 FLAG_NO_ROOT_GATE, FLAG_SCHED_REFILL, FLAG_SCHED_GROUPS = 1, 2, 4
 
@@ -95,6 +96,7 @@ def lib():
         L.rtx_trace_shade.argtypes = [C.c_void_p, C.POINTER(Options), _f, _f, C.c_uint32, C.c_int32, C.c_int32, _f]
         L.rtx_camera_points.argtypes = [C.c_void_p, C.POINTER(Camera), _f, C.c_uint32, _f, _f]
         L.rtx_scene_set_flags.argtypes = [C.c_void_p, C.c_uint32]
+        L.rtx_scene_get_packed_bvh.argtypes = [C.c_void_p, _u]
         L.rtx_tiles_count.argtypes = [Rect, C.c_int32, C.c_int32, C.c_int32]
         L.rtx_render_tiles_dev.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Options), Rect, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -237,6 +239,13 @@ class Scene:
         order = np.zeros(max(1, i.ntris), np.uint32)
         _check(lib().rtx_scene_get_bvh(self.h, nodes.ctypes.data_as(_u), order.ctypes.data_as(_u)))
         return nodes, order[:i.ntris]
+
+    def packed_bvh(self):
+        """[ngroups, 16] uint32: the 64-byte groups as the kernels load them."""
+        i = self.info()
+        g = np.zeros((max(1, i.nnodes // 4), 16), np.uint32)
+        _check(lib().rtx_scene_get_packed_bvh(self.h, g.ctypes.data_as(_u)))
+        return g[: i.nnodes // 4]
 
     def trace_closest(self, o, d, full=False):
         o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)

@@ -531,6 +531,16 @@ extern "C" int rtx_scene_get_bvh(const rtx_scene* s, uint32_t* nodes8, uint32_t*
   return RTX_OK;
 }
 
+extern "C" int rtx_scene_get_packed_bvh(const rtx_scene* s, uint32_t* groups16) {
+  if (!s) return fail(RTX_EINVAL, "null scene");
+  if (!s->built) return fail(RTX_ESTATE, "scene not built (rtx_scene_build / rtx_scene_commit)");
+  if (!groups16) return fail(RTX_EINVAL, "null argument");
+  std::vector<PackedGroup> g;
+  pack_groups(s->bvh.quads, &g);
+  std::memcpy(groups16, g.data(), g.size() * sizeof(PackedGroup));
+  return RTX_OK;
+}
+
 // ------------------------------------------------------------------ launch helpers
 static int grid_for(const rtx_scene* s, size_t items) {
   size_t blocks = (items + kBlock - 1) / kBlock;
