@@ -39,8 +39,8 @@ void build_bvh(const float* tri_lo, const float* tri_hi, uint32_t ntris, int thr
 
 // Collapses the binary tree into the layout the kernels walk: every internal node's two
 // children are replaced by their own children where those are internal, giving groups of up
-// to 4 sibling 32-byte nodes stored contiguously (128 bytes = one cache line per traversal
-// step instead of two dependent 64-byte fetches).  A slot is {lo, ref, hi, count}:
+// to 4 sibling 32-byte nodes stored contiguously (one fetch per traversal step instead of two
+// dependent ones; the kernels load the 64-byte PackedGroup form below).  A slot is {lo, ref, hi, count}:
 // count > 0 leaf over triangles [ref, ref+count); count == 0 internal, ref = index of its
 // child group; ref == kEmptySlot unused.  Fills out->quads / quad_depth / quad_slots.
 void collapse_to_quads(BvhBuildResult* out);
