@@ -175,6 +175,15 @@ int rtx_camera_points(rtx_scene*, const rtx_camera*, const float* ij, uint32_t n
  * src/Intersect.cpp:67-145): the slab-test t (may be negative), INFINITY on a miss. */
 int rtx_intersect_box(rtx_scene*, const float* bmin_xyz, const float* bmax_xyz, const float* origin_xyz,
                       const float* dir_xyz, uint32_t n, float* t);
+/* The hit search of Flyscene::ReflectDebugRay (src/flyscene.cpp:324-357) for n rays (o, d = its
+ * origin / dir arguments): closest triangle over the reference's leaf list, a leaf being scanned
+ * when the origin is inside its box (Box::isInBox, src/box.h:87-93) or the slab test gives t > 0;
+ * no spheres, no root gate.  face = mesh face id or -1, t = INFINITY on a miss, normal / point as
+ * HitInfo holds them.  box_flags (optional, n x number of leaves): 1 where the slab test passed
+ * from outside -- the boxes the reference highlights (ray_hitbox).  Needs the reference leaf
+ * list (rtx_scene_build_reference_leafboxes) before commit. */
+int rtx_debug_hit(rtx_scene*, const float* o, const float* d, uint32_t n, float* t, int32_t* face, float* normal,
+                  float* point, uint8_t* box_flags);
 
 /* Flyscene::traceRay(bounce, Ray(o,d), insideObject) for n rays (src/flyscene.cpp:587-601):
  * the shaded colour, 3 floats per ray. */

@@ -96,6 +96,11 @@ def lib():
         L.ora_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  _f, _f, C.POINTER(C.c_int32)]
         L.ora_ray_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.ora_debug_hit.argtypes = [C.c_void_p, _f, _f, C.c_int, C.c_void_p, C.POINTER(C.c_uint8)]
+        L.ora_debug_hit.restype = None
+        L.ora_debug_ray.argtypes = [C.c_void_p, _f, _f, C.c_int, _f, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_uint8), _f, C.c_int,
+                                    C.POINTER(C.c_int)]
+        L.ora_debug_ray.restype = C.c_int
         L.ora_box.restype = C.c_float
         L.ora_dot.restype = C.c_float
         L.ora_norm.restype = C.c_float
@@ -268,6 +273,29 @@ class Scene:
         out = np.zeros(len(o), HIT_DTYPE)
         lib().ora_closest_mt(self.h, fp(o), fp(d), len(o), threads, out.ctypes.data_as(C.c_void_p))
         return out
+
+    def num_leaves(self):
+        return int(lib().ora_scene_num_leaves(self.h))
+
+    def debug_hit(self, o, d, want_flags=False):
+        """Hit search of Flyscene::ReflectDebugRay: HIT_DTYPE array (+ [n, leaves] flags)."""
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        out = np.zeros(len(o), HIT_DTYPE)
+        flags = np.zeros((len(o), max(1, self.num_leaves())), np.uint8)
+        lib().ora_debug_hit(self.h, fp(o), fp(d), len(o), out.ctypes.data_as(C.c_void_p),
+                            flags.ctypes.data_as(C.POINTER(C.c_uint8)) if want_flags else None)
+        return (out, flags[:, :self.num_leaves()]) if want_flags else out
+
+    def debug_ray(self, origin, direction, jumps, max_segs=64):
+        """Flyscene::ReflectDebugRay as data: (segments [k, 8], faces [k], box flags [leaves], light segments [m, 7])."""
+        origin = np.ascontiguousarray(origin, np.float32); direction = np.ascontiguousarray(direction, np.float32)
+        segs = np.zeros((max_segs, 8), np.float32); faces = np.zeros(max_segs, np.int32)
+        flags = np.zeros(max(1, self.num_leaves()), np.uint8)
+        ls = np.zeros((max_segs * 8, 7), np.float32); nls = C.c_int(0)
+        k = lib().ora_debug_ray(self.h, fp(origin), fp(direction), int(jumps), fp(segs), faces.ctypes.data_as(C.POINTER(C.c_int32)),
+                                max_segs, flags.ctypes.data_as(C.POINTER(C.c_uint8)), fp(ls), len(ls), C.byref(nls))
+        return segs[:k], faces[:k], flags[:self.num_leaves()], ls[:nls.value]
 
     def visible(self, light, pos):
         light = np.ascontiguousarray(light, np.float32).reshape(-1, 3)

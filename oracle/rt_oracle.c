@@ -671,6 +671,65 @@ static void merge_counts(ora_scene* s, const counters* cn) {
   for (int i = 0; i < 5; ++i) s->counts[i] += cn->c[i];
   pthread_mutex_unlock(&s->mu);
 }
+/* The hit search of Flyscene::ReflectDebugRay (src/flyscene.cpp:324-357) for one (origin, dir):
+ * leaf list in order; a leaf is scanned when Box::isInBox(origin) (src/box.h:87-93) or when
+ * intersectBox gives t != INFINITY && t > 0 (then the box is recorded, ray_hitbox); strict <. */
+static ora_hit debug_hit(const ora_scene* s, v3 origin, v3 dir, uint8_t* box_flags) {
+  ora_hit best = hit_miss();
+  float smallestT = INFINITY;
+  for (int b = 0; b < s->nleaves; ++b) {
+    const leaf_t* L = &s->leaves[b];
+    int scan = (origin.x >= L->bmin.x && origin.x <= L->bmax.x) && (origin.y >= L->bmin.y && origin.y <= L->bmax.y) &&
+               (origin.z >= L->bmin.z && origin.z <= L->bmax.z);
+    if (!scan) {
+      float bt = intersect_box(L->bmin, L->bmax, origin, dir);
+      if (bt != INFINITY && bt > 0) { scan = 1; if (box_flags) box_flags[b] = 1; }
+    }
+    if (scan) {
+      phit h;
+      int i = intersect_triangles(s, s->leaf_faces + L->start, L->count, origin, dir, &h);
+      if (h.t != INFINITY && smallestT > h.t) {
+        smallestT = h.t;
+        best.t = h.t; best.face = s->leaf_faces[L->start + i]; st3(best.n, h.n); st3(best.p, h.p); best.mat = s->tri_mat[best.face];
+      }
+    }
+  }
+  return best;
+}
+void ora_debug_hit(const ora_scene* s, const float* o, const float* d, int n, ora_hit* out, uint8_t* box_flags) {
+  for (int i = 0; i < n; ++i) out[i] = debug_hit(s, ld3(o + 3 * i), ld3(d + 3 * i), box_flags ? box_flags + (size_t)i * s->nleaves : NULL);
+}
+/* Flyscene::ReflectDebugRay (src/flyscene.cpp:311-393) as data.  segs: 8 floats per segment
+ * {origin, dir as passed, length, hit flag (1 = ends on a surface; a miss is drawn 10 long)};
+ * seg_face: face id per segment; box_flags: OR over the bounces; light_segs: 7 floats per
+ * visible point light {hit point, normalised direction, distance}.  Returns the segment count. */
+int ora_debug_ray(const ora_scene* s, const float* origin, const float* dir, int jumps, float* segs, int32_t* seg_face, int max_segs,
+                  uint8_t* box_flags, float* light_segs, int max_light_segs, int* n_light_segs) {
+  v3 o = ld3(origin), d = ld3(dir);
+  int ns = 0, nl = 0;
+  for (int bounce = 0; bounce <= jumps && ns < max_segs; ++bounce) {
+    ray_t r = make_ray(o, d);
+    ora_hit h = debug_hit(s, o, d, box_flags);
+    float* sg = segs + 8 * ns;
+    st3(sg, o); st3(sg + 3, d);
+    if (h.t == INFINITY) { sg[6] = 10.0f; sg[7] = 0.0f; seg_face[ns++] = -1; break; }
+    sg[6] = h.t; sg[7] = 1.0f; seg_face[ns++] = h.face;
+    v3 P = ld3(h.p);
+    for (int i = 0; i < s->nlights; ++i) {
+      v3 light = ld3(s->lights + 3 * i);
+      int bm;
+      if (can_see_light(s, light, P, &bm, NULL, NULL) && nl < max_light_segs) {
+        float* lg = light_segs + 7 * nl++;
+        st3(lg, P); st3(lg + 3, normalized3(sub3(light, P))); lg[6] = norm3(sub3(light, P));
+      }
+    }
+    ray_t nr = reflect_ray(&r, ld3(h.n), P);
+    o = nr.o; d = nr.d;
+  }
+  if (n_light_segs) *n_light_segs = nl;
+  return ns;
+}
+
 void ora_ray_counts(const ora_scene* s, uint64_t out[5]) { for (int i = 0; i < 5; ++i) out[i] = s->counts[i]; }
 
 void ora_closest(const ora_scene* s, const float* o, const float* d, int n, ora_hit* out) {

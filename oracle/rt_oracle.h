@@ -77,6 +77,10 @@ int ora_scene_add_material(ora_scene*, const ora_mtl*);
 /* Flyscene::divideBox_KD (src/flyscene.cpp:1110-1185). Returns #leaves, or -1 when the
  * reference would never terminate (detected by an iteration cap). */
 int ora_scene_build_leafboxes(ora_scene*, int max_faces, long iter_cap);
+/* Flyscene::ReflectDebugRay (src/flyscene.cpp:311-393): its hit search per ray, and the whole walk as data. */
+void ora_debug_hit(const ora_scene*, const float* o, const float* d, int n, ora_hit* out, uint8_t* box_flags);
+int ora_debug_ray(const ora_scene*, const float* origin, const float* dir, int jumps, float* segs, int32_t* seg_face, int max_segs,
+                  uint8_t* box_flags, float* light_segs, int max_light_segs, int* n_light_segs);
 int ora_scene_num_leaves(const ora_scene*);
 int ora_scene_leaf(const ora_scene*, int i, float* bmin, float* bmax, int32_t* faces, int cap);
 void ora_scene_root_box(const ora_scene*, float* bmin, float* bmax);

@@ -52,7 +52,7 @@ SYMBOLS = ["rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_
            "rtx_trace_visible", "rtx_render", "rtx_render_dev", "rtx_tiles_count", "rtx_render_tiles_dev",
            "rtx_get_stats", "rtx_scene_build_reference_leafboxes", "rtx_scene_set_leafboxes",
            "rtx_scene_get_leafboxes", "rtx_intersect_box", "rtx_trace_shade", "rtx_camera_points", "rtx_scene_set_flags",
-           "rtx_scene_get_packed_bvh"]
+           "rtx_scene_get_packed_bvh", "rtx_debug_hit"]
 
 FLAG_NO_ROOT_GATE, FLAG_SCHED_REFILL, FLAG_SCHED_GROUPS = 1, 2, 4
 
@@ -97,6 +97,7 @@ def lib():
         L.rtx_camera_points.argtypes = [C.c_void_p, C.POINTER(Camera), _f, C.c_uint32, _f, _f]
         L.rtx_scene_set_flags.argtypes = [C.c_void_p, C.c_uint32]
         L.rtx_scene_get_packed_bvh.argtypes = [C.c_void_p, _u]
+        L.rtx_debug_hit.argtypes = [C.c_void_p, _f, _f, C.c_uint32, _f, C.POINTER(C.c_int32), _f, _f, C.POINTER(C.c_uint8)]
         L.rtx_tiles_count.argtypes = [Rect, C.c_int32, C.c_int32, C.c_int32]
         L.rtx_render_tiles_dev.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Options), Rect, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -239,6 +240,20 @@ class Scene:
         order = np.zeros(max(1, i.ntris), np.uint32)
         _check(lib().rtx_scene_get_bvh(self.h, nodes.ctypes.data_as(_u), order.ctypes.data_as(_u)))
         return nodes, order[:i.ntris]
+
+    def debug_hit(self, o, d, want_flags=False):
+        """rtx_debug_hit: (t, face, normal, point[, box_flags])."""
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        n = len(o)
+        t = np.zeros(n, np.float32); face = np.zeros(n, np.int32)
+        nrm = np.zeros((n, 3), np.float32); pt = np.zeros((n, 3), np.float32)
+        nl = C.c_uint32(); nf = C.c_uint32()
+        _check(lib().rtx_scene_get_leafboxes(self.h, None, None, None, None, None, C.byref(nl), C.byref(nf)))
+        flags = np.zeros((n, max(1, nl.value)), np.uint8) if want_flags else None
+        _check(lib().rtx_debug_hit(self.h, fp(o), fp(d), n, fp(t), face.ctypes.data_as(C.POINTER(C.c_int32)), fp(nrm), fp(pt),
+                                   flags.ctypes.data_as(C.POINTER(C.c_uint8)) if want_flags else None))
+        return (t, face, nrm, pt, flags[:, :nl.value]) if want_flags else (t, face, nrm, pt)
 
     def packed_bvh(self):
         """[ngroups, 16] uint32: the 64-byte groups as the kernels load them."""

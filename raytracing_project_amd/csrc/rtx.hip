@@ -1040,6 +1040,40 @@ extern "C" int rtx_intersect_box(rtx_scene* s, const float* bmin, const float* b
   return RTX_OK;
 }
 
+// The hit search of Flyscene::ReflectDebugRay (src/flyscene.cpp:324-357) for n rays.
+extern "C" int rtx_debug_hit(rtx_scene* s, const float* o, const float* d, uint32_t n, float* t, int32_t* face, float* normal,
+                             float* point, uint8_t* box_flags) {
+  if (int rc = check_ready(s)) return rc;
+  if (!s->have_leaves) return fail(RTX_ESTATE, "the debug ray walks the reference leaf list (rtx_scene_build_reference_leafboxes) before commit");
+  if (n == 0) return RTX_OK;
+  if (!o || !d || !t || !face || !normal || !point) return fail(RTX_EINVAL, "null argument");
+  const size_t b3 = (size_t)n * 12, nleaf = s->dev.nleafboxes;
+  if (int rc = s->w_io[0].ensure(b3)) return rc;
+  if (int rc = s->w_io[1].ensure(b3)) return rc;
+  if (int rc = s->w_io[2].ensure((size_t)n * 4)) return rc;
+  if (int rc = s->w_io[3].ensure((size_t)n * 4)) return rc;
+  if (int rc = s->w_io[4].ensure(b3)) return rc;
+  if (int rc = s->w_io[5].ensure(std::max<size_t>(1, (size_t)n * nleaf))) return rc;
+  if (int rc = s->w_rays[0].ensure((size_t)n * 32)) return rc;
+  HIP_TRY(hipMemcpyAsync(s->w_io[0].p, o, b3, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->w_io[1].p, d, b3, hipMemcpyHostToDevice, s->stream));
+  if (box_flags) HIP_TRY(hipMemsetAsync(s->w_io[5].p, 0, std::max<size_t>(1, (size_t)n * nleaf), s->stream));
+  hipLaunchKernelGGL(k_make_rays, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->w_io[0].as<float>(), s->w_io[1].as<float>(), n,
+                     s->w_rays[0].as<float4>());
+  // outputs: t -> io[2], face -> io[3], normal -> io[0], point -> io[4] (the xyz inputs are consumed by k_make_rays first)
+  hipLaunchKernelGGL(k_debug_hit, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->dev, s->w_rays[0].as<float4>(), n,
+                     s->w_io[2].as<float>(), s->w_io[3].as<int>(), s->w_io[0].as<float>(), s->w_io[4].as<float>(),
+                     box_flags ? s->w_io[5].as<unsigned char>() : nullptr);
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(t, s->w_io[2].p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(face, s->w_io[3].p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(normal, s->w_io[0].p, b3, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(point, s->w_io[4].p, b3, hipMemcpyDeviceToHost));
+  if (box_flags && nleaf) HIP_TRY(hipMemcpy(box_flags, s->w_io[5].p, (size_t)n * nleaf, hipMemcpyDeviceToHost));
+  return RTX_OK;
+}
+
 extern "C" int rtx_render(rtx_scene* s, const rtx_camera* cam, const rtx_options* opt, rtx_rect rect, float* rgb, float* t,
                           int32_t* face) {
   if (int rc = check_ready(s)) return rc;

@@ -1053,6 +1053,46 @@ __global__ __launch_bounds__(kBlock) void k_trace_gi(DevScene S, const float4* r
   }
 }
 
+// The closest-hit search of Flyscene::ReflectDebugRay (src/flyscene.cpp:324-357): over the
+// reference's flat leaf list, a leaf is scanned when the origin lies inside its box
+// (Box::isInBox, src/box.h:87-93) or when the slab test gives a positive distance (those boxes
+// are the ones the reference highlights: flags); strict < over leaves in list order, no
+// spheres, no root gate.  d1 = the direction after the Ray ctor's single normalisation, which
+// is what intersectTriangle / intersectBox see here (the debug path does not go through
+// getIntersections, so there is no second one).
+__global__ void k_debug_hit(DevScene S, const float4* rays, uint32_t n, float* t, int* face, float* normal, float* point,
+                            unsigned char* flags) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 ro = rays[2 * (size_t)i], rd = rays[2 * (size_t)i + 1];
+  const V3 o = v3(ro.x, ro.y, ro.z), d = v3(rd.x, rd.y, rd.z);
+  float smallest = INFINITY; int best_face = -1;
+  for (uint32_t b = 0; b < S.nleafboxes; ++b) {
+    const float4 lo = S.leafboxes[2 * b], hi = S.leafboxes[2 * b + 1];
+    const float blo[3] = {lo.x, lo.y, lo.z}, bhi[3] = {hi.x, hi.y, hi.z};
+    bool scan = (o.x >= lo.x && o.x <= hi.x) && (o.y >= lo.y && o.y <= hi.y) && (o.z >= lo.z && o.z <= hi.z);
+    if (!scan) {
+      const float bt = ref_box_t(o, d, blo, bhi);
+      if (bt != INFINITY && bt > 0) { scan = true; if (flags) flags[(size_t)i * S.nleafboxes + b] = 1; }
+    }
+    if (scan) {
+      Hit best; best.t = INFINITY; best.id = -1;
+      const uint32_t start = __float_as_uint(lo.w), cnt = __float_as_uint(hi.w);
+      for (uint32_t k = 0; k < cnt; ++k) {
+        Hit one; one.t = INFINITY; one.id = -1;
+        test_triangle(S, (uint32_t)S.face_pos[S.leaf_faces[start + k]], o, d, &one);
+        if (one.t < best.t) best = one;               // intersectTriangle: strict < in list order
+      }
+      if (best.t != INFINITY && smallest > best.t) { smallest = best.t; best_face = best.id; }
+    }
+  }
+  t[i] = smallest; face[i] = best_face;
+  V3 N = v3(0, 0, 0), P = v3(0, 0, 0);
+  if (best_face >= 0) { const float4 nm = S.face_nm[best_face]; N = v3(nm.x, nm.y, nm.z); P = point_on_ray(o, d, smallest); }
+  normal[3 * i] = N.x; normal[3 * i + 1] = N.y; normal[3 * i + 2] = N.z;
+  point[3 * i] = P.x; point[3 * i + 1] = P.y; point[3 * i + 2] = P.z;
+}
+
 // canSeeLight over caller (light, position) pairs: ray construction and decision.
 __global__ void k_make_shadow_rays(const float* light, const float* pos, uint32_t n, float4* rays) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -450,6 +450,42 @@ class Flyscene {
     rtx_check(rtx_camera_points(scene, &cam, p.v, 1, w.v, nullptr));
     return w;
   }
+  // ---- debug ray (src/flyscene.cpp:288-393), as data instead of Tucano cylinders: `rays` = the
+  // polyline (white segments end on a surface, the last one is 10 long when it left the scene),
+  // `ray_hitbox` = indices of the leaf boxes the ray entered from outside, `light_rays` = segments
+  // from hit points to the lights that see them.  `jumps` = number of reflections followed
+  // (src/flyscene.hpp:124, keys in src/flyscene.cpp:238-249).
+  struct DebugSegment { Vector3f origin, dir; float length; bool hit; int faceId; };
+  std::vector<DebugSegment> rays, light_rays;
+  std::vector<int> ray_hitbox;
+  int jumps = 0;
+  void createDebugRay(const Vector2f& mouse_pos) {
+    rays.clear(); ray_hitbox.clear(); light_rays.clear();
+    Vector3f screen_pos = screenToWorld(mouse_pos);
+    Vector3f dir = (screen_pos - getCenter()).normalized();
+    ReflectDebugRay(getCenter(), dir, 0, jumps);
+  }
+  void ReflectDebugRay(Vector3f origin, Vector3f dir, int bounce, int jumps_) {
+    sync();
+    uint32_t nl = 0, nf = 0;
+    rtx_check(rtx_scene_get_leafboxes(scene, nullptr, nullptr, nullptr, nullptr, nullptr, &nl, &nf));
+    std::vector<uint8_t> flags(nl ? nl : 1);
+    for (; bounce <= jumps_; ++bounce) {
+      Ray r(origin, dir);
+      HitInfo h;
+      std::fill(flags.begin(), flags.end(), 0);
+      rtx_check(rtx_debug_hit(scene, origin.v, dir.v, 1, &h.t, &h.faceId, h.normal.v, h.point.v, flags.data()));
+      for (uint32_t i = 0; i < nl; ++i)
+        if (flags[i]) ray_hitbox.push_back((int)i);
+      if (h.t == INFINITY) { rays.push_back({origin, dir, 10.0f, false, -1}); return; }
+      rays.push_back({origin, dir, h.t, true, h.faceId});
+      for (size_t i = 0; i < lights.size(); ++i)
+        if (canSeeLight(lights[i], h.point).first)
+          light_rays.push_back({h.point, (lights[i] - h.point).normalized(), (lights[i] - h.point).norm(), true, -1});
+      Ray nr = r.reflectRay(h.normal, h.point);
+      origin = nr.getOrigin(); dir = nr.getDirection();
+    }
+  }
   const rtx_stats& lastStats() { rtx_get_stats(scene, &stats); return stats; }
   void markCameraChanged() { frame_dirty = true; }
 

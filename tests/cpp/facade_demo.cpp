@@ -38,6 +38,20 @@ int main(int argc, char** argv) {
       Vector3f col = fs.traceRay(0, r, false);
       std::printf("rgb %.9g %.9g %.9g\n", col[0], col[1], col[2]);
     }
+    // debug rays (src/flyscene.cpp:288-393): the first rays again, followed through 3 reflections
+    in.clear(); in.seekg(0);
+    for (int k = 0; k < 12 && (in >> o[0] >> o[1] >> o[2] >> d[0] >> d[1] >> d[2]); ++k) {
+      fs.rays.clear(); fs.ray_hitbox.clear(); fs.light_rays.clear();
+      fs.ReflectDebugRay(Vector3f(o[0], o[1], o[2]), Vector3f(d[0], d[1], d[2]), 0, 3);
+      std::printf("debug %zu %zu %zu\n", fs.rays.size(), fs.ray_hitbox.size(), fs.light_rays.size());
+      for (const auto& sgm : fs.rays)
+        std::printf("seg %.9g %.9g %.9g %.9g %.9g %.9g %.9g %d %d\n", sgm.origin[0], sgm.origin[1], sgm.origin[2], sgm.dir[0], sgm.dir[1],
+                    sgm.dir[2], sgm.length, sgm.hit ? 1 : 0, sgm.faceId);
+      for (int b : fs.ray_hitbox) std::printf("hitbox %d\n", b);
+      for (const auto& sgm : fs.light_rays)
+        std::printf("lseg %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", sgm.origin[0], sgm.origin[1], sgm.origin[2], sgm.dir[0], sgm.dir[1],
+                    sgm.dir[2], sgm.length);
+    }
     fs.raytraceScene(W, W);       // adds the 13 spheres, renders, writes result.ppm
     const rtx_stats& st = fs.lastStats();
     std::printf("frame rays %llu %llu %llu %llu %llu\n", (unsigned long long)st.rays_primary, (unsigned long long)st.rays_shadow,

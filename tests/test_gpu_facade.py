@@ -1,7 +1,7 @@
 """The C++ drop-in facade (raytracing_project_amd/host/flyscene.hpp) driven like the reference's
 own callers (tests/cpp/facade_demo.cpp), checked against the oracle.  Exercises, through the
 reference's method names: initialize (OBJ/MTL import), getIntersections, intersectTriangle,
-intersectBox, canSeeLight, traceRay, raytraceScene (13 spheres, result.ppm)."""
+intersectBox, canSeeLight, traceRay, ReflectDebugRay, raytraceScene (13 spheres, result.ppm)."""
 import os
 import subprocess
 
@@ -89,6 +89,25 @@ def test_facade_matches_oracle(tmp_path, oa):
         l = next(it)
         assert l[0] == "rgb"
         assert np.allclose(f32(l[1:4]), rgb[i], rtol=1e-4, atol=1e-6)
+    # debug rays: ReflectDebugRay through 3 reflections for the first 12 rays (raw direction, as the demo passes it)
+    for i in range(12):
+        l = next(it)
+        assert l[0] == "debug"
+        nseg, nbox, nls = int(l[1]), int(l[2]), int(l[3])
+        segs, faces, flags, ls = o.debug_ray(org[i], d[i], 3)
+        assert nseg == len(segs) and nls == len(ls)
+        for k in range(nseg):
+            l = next(it)
+            assert l[0] == "seg" and np.array_equal(f32(l[1:8]), segs[k, :7]) and int(l[8]) == int(segs[k, 7]) and int(l[9]) == faces[k]
+        boxes = set()
+        for k in range(nbox):
+            l = next(it)
+            assert l[0] == "hitbox"
+            boxes.add(int(l[1]))
+        assert boxes == set(np.nonzero(flags)[0].tolist())
+        for k in range(nls):
+            l = next(it)
+            assert l[0] == "lseg" and np.array_equal(f32(l[1:8]), ls[k])
     # raytraceScene: planeobj + 13 spheres, reference options, result.ppm
     cr, ka, kd = scenes.reference_spheres()
     ids = [o.add_material(oa.make_mtl(ka=tuple(ka[i]), kd=tuple(kd[i]), ks=(.5, .5, .5), ns=10, ni=1, d=0, illum=2))

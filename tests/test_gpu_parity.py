@@ -574,3 +574,35 @@ def test_nasty_geometry_random_rays_vs_bruteforce(api, oa):
     assert_bits_equal(tt, ot, "t (render)")
     assert_rgb_close(rgb, orgb, "nasty render")
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["planeobj", "cube", "twoObjects", "toy"])
+def test_debug_hit_vs_oracle(api, oa, name):
+    """rtx_debug_hit == the hit search of Flyscene::ReflectDebugRay (leaf list, isInBox / t > 0
+    gates, highlighted boxes) as restated in the oracle; parity unpinned beyond the oracle (the
+    survey recorded no debug-ray output of the reference)."""
+    fx = load_scene_fixture(name)
+    s = api.Scene(fx["verts"], fx["idx"], fx["tri_mat"], rtx_materials(fx["mats"]))
+    s.set_lights([[-1.0, 1.0, 1.0]])
+    assert s.build_reference_leafboxes() == int(fx["leaves"]) > 0
+    s.commit(0)
+    o = oa.Scene(fx["verts"], fx["idx"], fx["tri_mat"], oracle_materials(fx["mats"]))
+    assert o.build_leafboxes() == int(fx["leaves"])
+    rng = np.random.default_rng(11)
+    lo, hi = fx["verts"].min(0), fx["verts"].max(0)
+    n = 3000
+    org = rng.uniform(lo - 0.6 * (hi - lo) - 0.2, hi + 0.6 * (hi - lo) + 0.2, (n, 3)).astype(np.float32)
+    org[::3] = rng.uniform(lo, hi, (len(org[::3]), 3)).astype(np.float32)        # origins inside the leaf boxes
+    tgt = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    d = (tgt - org).astype(np.float32)
+    d[::17] = rng.normal(size=(len(d[::17]), 3)).astype(np.float32)
+    t, face, nrm, pt, flags = s.debug_hit(org, d, want_flags=True)
+    h, oflags = o.debug_hit(org, d, want_flags=True)
+    assert (h["face"] >= 0).sum() > n // 10
+    assert np.array_equal(face, h["face"])
+    assert_bits_equal(t, h["t"], "t")
+    assert_bits_equal(nrm, h["n"], "normal")
+    assert_bits_equal(pt, h["p"], "point")
+    assert np.array_equal(flags, oflags) and flags.any()
+    s.close()
