@@ -305,18 +305,35 @@ __device__ __forceinline__ bool node_step(const DevScene& S, const StackT& stk, 
   const float by = __builtin_fmaf(__uint_as_float(h0.y), ivy, -oiy);
   const float bz = __builtin_fmaf(__uint_as_float(h0.z), ivz, -oiz);
   const uint32_t ents[4] = {h1.x, h1.y, h1.z, h1.w};
+  // Which plane of each axis the ray enters through depends on the sign of the direction only:
+  // pick the words once per step instead of a min and a max per child and axis.  An unused slot
+  // is encoded inverted (lower planes 255, upper planes 0), so that its entry lies beyond its
+  // exit whatever the signs -- no separate "empty" test.
+  const bool nx = ivx < 0.0f, ny = ivy < 0.0f, nz = ivz < 0.0f;
+  const uint32_t wnx = nx ? h2.w : h2.x, wfx = nx ? h2.x : h2.w;
+  const uint32_t wny = ny ? h3.x : h2.y, wfy = ny ? h2.y : h3.x;
+  const uint32_t wnz = nz ? h3.y : h2.z, wfz = nz ? h2.z : h3.y;
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az}, bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
   float tn[4]; uint32_t en[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int sh = 8 * k;
-    const float x0 = __builtin_fmaf((float)((h2.x >> sh) & 0xFFu), ax, bx), x1 = __builtin_fmaf((float)((h2.w >> sh) & 0xFFu), ax, bx);
-    const float y0 = __builtin_fmaf((float)((h2.y >> sh) & 0xFFu), ay, by), y1 = __builtin_fmaf((float)((h3.x >> sh) & 0xFFu), ay, by);
-    const float z0 = __builtin_fmaf((float)((h2.z >> sh) & 0xFFu), az, bz), z1 = __builtin_fmaf((float)((h3.y >> sh) & 0xFFu), az, bz);
-    // entry clamped to the ray start, exit to the pruning limit: hit <=> entry <= exit
-    const float n_ = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
-    const float f_ = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), lim));
-    en[k] = ents[k];
-    tn[k] = ((n_ <= f_) && (en[k] != kEmptyRef)) ? n_ : INFINITY;
+  for (int k = 0; k < 4; k += 2) {
+    const int s0 = 8 * k, s1 = 8 * k + 8;
+    // two children per packed fma
+    const f2 qnx = {(float)((wnx >> s0) & 0xFFu), (float)((wnx >> s1) & 0xFFu)}, qfx = {(float)((wfx >> s0) & 0xFFu), (float)((wfx >> s1) & 0xFFu)};
+    const f2 qny = {(float)((wny >> s0) & 0xFFu), (float)((wny >> s1) & 0xFFu)}, qfy = {(float)((wfy >> s0) & 0xFFu), (float)((wfy >> s1) & 0xFFu)};
+    const f2 qnz = {(float)((wnz >> s0) & 0xFFu), (float)((wnz >> s1) & 0xFFu)}, qfz = {(float)((wfz >> s0) & 0xFFu), (float)((wfz >> s1) & 0xFFu)};
+    const f2 tnx = __builtin_elementwise_fma(qnx, ax2, bx2), tfx = __builtin_elementwise_fma(qfx, ax2, bx2);
+    const f2 tny = __builtin_elementwise_fma(qny, ay2, by2), tfy = __builtin_elementwise_fma(qfy, ay2, by2);
+    const f2 tnz = __builtin_elementwise_fma(qnz, az2, bz2), tfz = __builtin_elementwise_fma(qfz, az2, bz2);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      // entry clamped to the ray start, exit to the pruning limit: hit <=> entry <= exit
+      const float n_ = fmaxf(fmaxf(tnx[j], tny[j]), fmaxf(tnz[j], 0.0f));
+      const float f_ = fminf(fminf(tfx[j], tfy[j]), fminf(tfz[j], lim));
+      en[k + j] = ents[k + j];
+      tn[k + j] = (n_ <= f_) ? n_ : INFINITY;
+    }
   }
   // sort the 4 candidates near-to-far (5 compare-exchanges); misses carry tn = +inf
 #define RTX_CX(i, j) { const bool sw = tn[j] < tn[i]; const float tt_ = sw ? tn[j] : tn[i]; tn[j] = sw ? tn[i] : tn[j]; tn[i] = tt_; \
