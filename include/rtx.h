@@ -144,8 +144,8 @@ int rtx_scene_get_info(const rtx_scene*, rtx_scene_info*);
  * fp32 source of both.) */
 int rtx_scene_get_bvh(const rtx_scene*, uint32_t* nodes8, uint32_t* tri_face);
 /* The same groups in the 64-byte encoding the kernels load: nnodes / 4 x 16 words
- * {origin.xyz (float), exps, entry[4], lox, loy, loz, hix, hiy, hiz, 0, 0}; plane = origin +
- * byte * 2^(exp - 127) per axis (byte k of a plane word = child k, byte a of exps = axis a), rounded
+ * {origin.xyz, step_x (floats), entry[4], lox, loy, loz, hix, hiy, hiz, step_y, step_z (floats)}; plane =
+ * origin + byte * step per axis (byte k of a plane word = child k; steps are powers of two), rounded
  * outwards; entry = 0x80000000 | count << 28 | first triangle (leaf), child group (internal),
  * 0xFFFFFFFF (unused).  Inspection only (tests); no counterpart in the reference. */
 int rtx_scene_get_packed_bvh(const rtx_scene*, uint32_t* groups16);

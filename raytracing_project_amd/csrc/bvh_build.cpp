@@ -298,7 +298,7 @@ void pack_groups(const std::vector<BvhNode>& quads, std::vector<PackedGroup>* ou
       for (int a = 0; a < 3; ++a) { glo[a] = std::min(glo[a], q[k].lo[a]); ghi[a] = std::max(ghi[a], q[k].hi[a]); }
     }
     uint32_t planes[6] = {0, 0, 0, 0, 0, 0};   // lox loy loz hix hiy hiz
-    P.exps = 0;
+    float steps[3] = {0, 0, 0};
     for (int a = 0; a < 3; ++a) {
       if (!any) { glo[a] = 0.0f; ghi[a] = 0.0f; }
       P.origin[a] = glo[a];
@@ -312,7 +312,7 @@ void pack_groups(const std::vector<BvhNode>& quads, std::vector<PackedGroup>* ou
         while (e < 254 && top(e) < ghi[a]) ++e;
       }
       float step; { uint32_t b = (uint32_t)e << 23; std::memcpy(&step, &b, 4); }
-      P.exps |= (uint32_t)e << (8 * a);
+      steps[a] = step;
       for (int k = 0; k < 4; ++k) {
         uint32_t ql = 255, qh = 0;                              // unused slot (the entry says so)
         if (!(q[k].leftFirst == kEmptySlot && q[k].count == 0)) {
@@ -328,6 +328,7 @@ void pack_groups(const std::vector<BvhNode>& quads, std::vector<PackedGroup>* ou
         planes[3 + a] |= qh << (8 * k);
       }
     }
+    P.step_x = steps[0]; P.step_y = steps[1]; P.step_z = steps[2];
     P.lox = planes[0]; P.loy = planes[1]; P.loz = planes[2]; P.hix = planes[3]; P.hiy = planes[4]; P.hiz = planes[5];
     for (int k = 0; k < 4; ++k) {
       const BvhNode& nd = q[k];

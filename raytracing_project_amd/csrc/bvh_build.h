@@ -49,17 +49,18 @@ void collapse_to_quads(BvhBuildResult* out);
 // fp32 layout, and the L1 return path is what bounds the traversal kernels): child boxes are
 // 8-bit fixed point relative to the group's own bounds, rounded outwards.
 //   origin[3]   group lower corner (fp32)
-//   exps        byte a = biased exponent of the power-of-two step of axis a (step = 2^(e-127))
+//   step_x/y/z  power-of-two step of each axis (fp32, 2^e with e chosen so that 255 steps span the group)
 //   entry[4]    traversal entries: leaf = 0x80000000 | count << 28 | first triangle,
 //               internal = child group index, unused = 0xFFFFFFFF
 //   lox..hiz    byte k = child k's plane in steps from origin (lower planes rounded down,
-//               upper planes rounded up)
+//               upper planes rounded up); an unused slot has lower planes 255 and upper planes 0
 struct PackedGroup {
   float origin[3];
-  uint32_t exps;
+  float step_x;
   uint32_t entry[4];
   uint32_t lox, loy, loz, hix;
-  uint32_t hiy, hiz, pad0, pad1;
+  uint32_t hiy, hiz;
+  float step_y, step_z;
 };
 static_assert(sizeof(PackedGroup) == 64, "packed group must be 64 bytes");
 void pack_groups(const std::vector<BvhNode>& quads, std::vector<PackedGroup>* out);
