@@ -251,9 +251,9 @@ __device__ __forceinline__ bool block_slot(const DevCamera& C, uint32_t block, u
 }
 
 // ---------------------------------------------------------------- kernels
-// Persistent waves: the grid is sized to what is resident (8 blocks of 4 waves per CU) and
-// every wave walks its own static sequence of 64-ray chunks (struct Work), so expensive and
-// cheap regions of the image balance without any block-level synchronisation or atomics.
+// Persistent waves: the grid is sized to what is resident (7 or 8 blocks of 4 waves per CU).  A
+// block owns a fixed, image-wide scattered set of 64-ray units and its four waves (one per SIMD
+// of the CU) draw from it through a counter in LDS (struct Work): no global atomics.
 template <int kLds>
 __device__ __forceinline__ Stack<kLds> make_stack(uint32_t* lds, uint32_t* ovf) {
   Stack<kLds> st;
@@ -263,24 +263,30 @@ __device__ __forceinline__ Stack<kLds> make_stack(uint32_t* lds, uint32_t* ovf) 
   st.ovf_stride = gridDim.x * kBlock;
   return st;
 }
-// Work distribution: wave w of the grid takes the `grab`-ray units w, w + W, w + 2W, ...
-// (W = waves in the grid) -- no atomics.  Measured alternatives: one global cursor
-// (agent-scope atomics run at ~90 per us on this part whatever the address, and serialise),
-// and 64 per-stripe counters with XCD-local homes (better balance, mean wave busy time 67% ->
-// 85% of the kernel, but no faster: the kernels are bound by the L1 return path, which the
-// early-finishing waves leave to the others).
+// Work distribution: block b owns the unit quads b, b + B, b + 2B, ... (B = blocks in the grid; a
+// quad = the four 8x8 tiles of a 16x16 pixel block, or 256 consecutive queue rays) and its waves
+// take the next unit of that list with an LDS atomic, so the four SIMDs of a CU finish together
+// whatever the single units cost.  Measured alternatives: fully static lists per
+// wave (1.5-3% slower: the longest wave of a block runs on alone), one global cursor, 64
+// per-stripe global counters and a global pool for the last quarter (agent-scope atomics run at
+// ~90 per us on this part whatever the address, and serialise).
 struct Work {
-  uint32_t n, grab, next_base, step;
+  uint32_t n, grab;
+  lds_u32* ctr;       // the block's unit counter (LDS)
   __device__ __forceinline__ bool next(uint32_t* base) {
-    *base = next_base;
-    next_base += step;
-    return *base < n;
+    uint32_t i = 0;
+    if ((threadIdx.x & 63u) == 0) i = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+    // the block's units: quads of consecutive units (the four 8x8 tiles of a 16x16 pixel block), a grid apart
+    const uint32_t unit = ((i >> 2) * gridDim.x + blockIdx.x) * 4u + (i & 3u);
+    *base = unit * grab;
+    return unit < (n + grab - 1u) / grab;
   }
 };
-__device__ __forceinline__ Work make_work(uint32_t n, uint32_t grab) {
-  Work w; w.n = n; w.grab = grab;
-  w.next_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * grab));
-  w.step = gridDim.x * (kBlock / 64) * grab;
+__device__ __forceinline__ Work make_work(uint32_t n, uint32_t grab, uint32_t* ctr) {
+  Work w; w.n = n; w.grab = grab; w.ctr = (lds_u32*)ctr;
+  if (threadIdx.x == 0) *ctr = 0;
+  __syncthreads();
   return w;
 }
 
@@ -578,7 +584,8 @@ __global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_tra
                                                           uint2* hits) {
   __shared__ uint32_t lds_stack[(kRefill ? kLdsStack : kLdsStackGroups) * kBlock];
   CameraSource src; src.C = C;
-  const Work work = make_work(nblocks * (uint32_t)kBlock, grab);
+  __shared__ uint32_t lds_ctr;
+  const Work work = make_work(nblocks * (uint32_t)kBlock, grab, &lds_ctr);
   if constexpr (kRefill) {
     __shared__ uint32_t lds_wbuf[(kBlock / 64) * kWbufWords * 64];
     trace_wave(S, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), hits);
@@ -593,7 +600,8 @@ __global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_tra
                                                          uint32_t bounded, uint32_t grab, uint32_t* ovf, uint2* hits) {
   __shared__ uint32_t lds_stack[(kRefill ? kLdsStack : kLdsStackGroups) * kBlock];
   QueueSource src; src.rays = rays; src.bounded = bounded; src.anyhit = ((bounded & 2u) && (S.flags & 2u)) ? 1u : 0u;
-  const Work work = make_work(*count * stride, grab);
+  __shared__ uint32_t lds_ctr;
+  const Work work = make_work(*count * stride, grab, &lds_ctr);
   if constexpr (kRefill) {
     __shared__ uint32_t lds_wbuf[(kBlock / 64) * kWbufWords * 64];
     trace_wave(S, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), hits);
