@@ -210,3 +210,114 @@ void ora_camera_rays(const ora_camera* cam, int x0, int y0, int x1, int y1, floa
       normalize3f(dir, d1 + 3 * k);
     }
 }
+
+/* ---- wave-level replay (scheduling studies; scripts/wave_sim.py) --------------------------------
+ * Walks the rays o/d1[0..n) the way one 64-lane wave of trace_wave() would: setup 64 at a time,
+ * survivors parked, idle lanes refilled once `refill_min` are idle, leaf tests deferred until
+ * `defer_min` lanes want one.  speculate != 0: a lane that reaches a leaf while the wave is not in
+ * a leaf phase keeps the leaf in a pending slot (`speculate` of them, at most 4; a leaf phase tests the
+ * oldest) and goes on with the next stack entry; block_min: a leaf phase also starts once that many lanes
+ * can do nothing else (0 = off).
+ * The hits must not depend on any of this (t/face are returned to check exactly that).
+ * stats: [0] node phases, [1] lanes in them, [2] leaf phases, [3] triangle passes (sum of the
+ * phase's largest leaf), [4] lane-triangles, [5] setup rounds, [6] node steps in total. */
+#define WS_NONE 0x7FFFFFFFu
+typedef struct {
+  float o[3], d[3], iv[3], oi[3], best_t; int best_id; uint32_t cur, pend[4]; int npend; uint32_t stack[96]; int sp; int ray;
+} ws_lane;
+
+static void ws_node_step(const bvh_job* j, ws_lane* L) {
+  const uint32_t* q = j->nodes + 32 * (size_t)L->cur;
+  float lim = L->best_t * PRUNE_SLACK, tn[4];
+  uint32_t en[4];
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t* nd = q + 8 * k;
+    float n_, f_;
+    slab(nd, L->iv, L->oi, &n_, &f_);
+    uint32_t ref = nd[3], c = nd[7];
+    n_ = fmaxf(n_, 0.0f); f_ = fminf(f_, lim);
+    int h = (n_ <= f_) && (ref != 0xFFFFFFFFu);
+    tn[k] = h ? n_ : INFINITY;
+    en[k] = c ? (LEAF_BIT | (c << 28) | ref) : ref;
+  }
+#define CX(a, b) do { if (tn[b] < tn[a]) { float tf_ = tn[a]; tn[a] = tn[b]; tn[b] = tf_; uint32_t te_ = en[a]; en[a] = en[b]; en[b] = te_; } } while (0)
+  CX(0, 1); CX(2, 3); CX(0, 2); CX(1, 3); CX(1, 2);
+#undef CX
+  if (tn[0] != INFINITY) {
+    if (tn[3] != INFINITY) L->stack[L->sp++] = en[3];
+    if (tn[2] != INFINITY) L->stack[L->sp++] = en[2];
+    if (tn[1] != INFINITY) L->stack[L->sp++] = en[1];
+    L->cur = en[0];
+  } else {
+    L->cur = L->sp ? L->stack[--L->sp] : WS_NONE;
+  }
+}
+
+void ora_wave_sim(const uint32_t* nodes8, const float* tri16, const int32_t* tri_face, uint32_t ntris, uint32_t nwild,
+                  const float* root_lo, const float* root_hi, const float* o, const float* d1, int n, int refill_min,
+                  int defer_min, int speculate, int block_min, float* t, int32_t* face, uint64_t* stats) {
+  bvh_job job; memset(&job, 0, sizeof job);
+  job.nodes = nodes8; job.tris = tri16; job.tri_face = tri_face; job.ntris = ntris; job.nwild = nwild;
+  static ws_lane lanes[64], parked[64];
+  int nparked = 0, next = 0;
+  for (int i = 0; i < 64; ++i) { lanes[i].cur = WS_NONE; lanes[i].npend = 0; }
+  for (int i = 0; i < 7; ++i) stats[i] = 0;
+  for (;;) {
+    int idle = 0;
+    for (int i = 0; i < 64; ++i) idle += lanes[i].cur == WS_NONE && lanes[i].npend == 0;
+    if ((idle >= refill_min || idle == 64) && (nparked || next < n)) {
+      while (nparked == 0 && next < n) {
+        stats[5]++;
+        for (int r = next; r < next + 64 && r < n; ++r) {
+          ws_lane* L = &parked[nparked];
+          memcpy(L->o, o + 3 * r, 12);
+          normalize3f(d1 + 3 * r, L->d);
+          L->best_t = INFINITY; L->best_id = -1; L->ray = r; L->sp = 0; L->npend = 0; L->cur = 0;
+          if (ntris && gate(L->o, L->d, root_lo, root_hi) != INFINITY) {
+            for (int k = 0; k < 3; ++k) { L->iv[k] = 1.0f / L->d[k]; if (!(fabsf(L->iv[k]) <= 1e18f)) L->iv[k] = copysignf(1e18f, L->d[k]); L->oi[k] = L->o[k] * L->iv[k]; }
+            for (uint32_t k = ntris - nwild; k < ntris; ++k) tri_test(&job, k, L->o, L->d, &L->best_t, &L->best_id);
+            if (nwild < ntris) { ++nparked; continue; }
+          }
+          t[r] = L->best_t; face[r] = L->best_id;
+        }
+        next += 64;
+      }
+      for (int i = 0; i < 64 && nparked; ++i)
+        if (lanes[i].cur == WS_NONE && lanes[i].npend == 0) lanes[i] = parked[--nparked];
+    }
+    int n_node = 0, n_leaf = 0, n_blocked = 0;
+    uint8_t at_node[64], want_leaf[64];
+    for (int i = 0; i < 64; ++i) {
+      const ws_lane* L = &lanes[i];
+      at_node[i] = L->cur != WS_NONE && !(L->cur & LEAF_BIT);
+      want_leaf[i] = L->npend != 0 || (L->cur != WS_NONE && (L->cur & LEAF_BIT));
+      n_node += at_node[i]; n_leaf += want_leaf[i]; n_blocked += want_leaf[i] && !at_node[i];
+    }
+    if (n_node == 0 && n_leaf == 0) break;
+    if (n_node) {
+      stats[0]++; stats[1] += (uint64_t)n_node; stats[6] += (uint64_t)n_node;
+      for (int i = 0; i < 64; ++i) if (at_node[i]) ws_node_step(&job, &lanes[i]);
+    }
+    if (n_leaf && (n_node == 0 || n_leaf >= defer_min || (block_min && n_blocked >= block_min))) {
+      uint32_t maxcnt = 0;
+      for (int i = 0; i < 64; ++i) if (want_leaf[i]) {
+        ws_lane* L = &lanes[i];
+        const int from_pend = L->npend != 0;
+        const uint32_t leaf = from_pend ? L->pend[0] : L->cur;
+        const uint32_t first = leaf & 0x0FFFFFFFu, cnt = (leaf >> 28) & 7u;
+        if (cnt > maxcnt) maxcnt = cnt;
+        stats[4] += cnt;
+        for (uint32_t k = first; k < first + cnt; ++k) tri_test(&job, k, L->o, L->d, &L->best_t, &L->best_id);
+        if (from_pend) { for (int k = 1; k < L->npend; ++k) L->pend[k - 1] = L->pend[k]; --L->npend; } else L->cur = L->sp ? L->stack[--L->sp] : WS_NONE;
+      }
+      stats[2]++; stats[3] += maxcnt;
+    }
+    for (int i = 0; i < 64; ++i) {
+      ws_lane* L = &lanes[i];
+      if (L->npend < speculate && L->cur != WS_NONE && (L->cur & LEAF_BIT)) {
+        L->pend[L->npend++] = L->cur; L->cur = L->sp ? L->stack[--L->sp] : WS_NONE;
+      }
+      if ((at_node[i] || want_leaf[i]) && L->cur == WS_NONE && L->npend == 0) { t[L->ray] = L->best_t; face[L->ray] = L->best_id; }
+    }
+  }
+}

@@ -21,6 +21,12 @@
 #ifndef RTX_DEFER_MIN
 #define RTX_DEFER_MIN 24    // lanes at leaves before the triangle tests run (while node work exists)
 #endif
+#ifndef RTX_SPEC
+#define RTX_SPEC 1         // 1: lanes go on past a pending leaf; 0: they wait at it (A/B switch); 2: on, except for any-blocker shadow rays
+#endif
+#ifndef RTX_BLOCK_MIN
+#define RTX_BLOCK_MIN 8     // ... or lanes that hold a leaf and have no node work
+#endif
 
 namespace rtx {
 
@@ -135,12 +141,15 @@ __device__ __forceinline__ void test_triangle(const DevScene& S, uint32_t k, V3 
   const float4 qn = S.tris[4 * k];                 // n, D
   const V3 n = v3(qn.x, qn.y, qn.z);
   const float den = dot(n, d);
-  if (den == 0.0f) return;
   const float num = qn.w - dot(o, n);
   // (A reciprocal-based pre-rejection of t was measured here: 87 % of the triangles a ray reaches
   // pass the plane stage, so it cost more than the divisions it saved.)
+  // den == 0 (the reference returns early) is folded into this test rather than branched on, so
+  // that {n, D} stays one 16-byte load: with a branch in between the compiler fetches D separately,
+  // a second round trip on the critical path.
   const float t = num / den;
-  if (!(t >= kPrecision && t <= best->t)) return;
+  if (!(den != 0.0f && t >= kPrecision && t <= best->t)) return;
+  // (fetching these three before the test above, for one round trip instead of two, measured equal)
   const float4 q0 = S.tris[4 * k + 1];             // v0, vv
   const float4 q1 = S.tris[4 * k + 2];             // u, uu
   const float4 q2 = S.tris[4 * k + 3];             // v, uv
@@ -411,6 +420,7 @@ struct QueueSource {
 constexpr uint32_t kDone = 0x7FFFFFFFu;   // lane holds no ray (never a valid entry: group indices stay below 2^25)
 constexpr int kRefillMin = RTX_REFILL_MIN;
 constexpr int kDeferMin = RTX_DEFER_MIN;
+constexpr int kBlockMin = RTX_BLOCK_MIN;
 constexpr int kWbufWords = 9;             // o.xyz, d.xyz, best.t, best.id, slot
 
 template <class Source>
@@ -423,12 +433,12 @@ __device__ __forceinline__ void trace_wave(const DevScene& S, const Source& src,
   V3 o = v3(0, 0, 0), d = v3(0, 0, 0);
   float ivx = 0, ivy = 0, ivz = 0, oix = 0, oiy = 0, oiz = 0;
   Hit best; best.t = INFINITY; best.id = -1;
-  uint32_t cur = kDone, slot = 0;
+  uint32_t cur = kDone, pend = kDone, slot = 0;   // pend: a leaf reached outside a leaf phase, tested at the next one
   int sp = 0;
 
   for (;;) {
-    // entry kinds: leaf = top bit set, node group = below kDone, no ray = kDone
-    uint64_t act = __ballot(cur != kDone);
+    // entry kinds: leaf = top bit set, node group = below kDone, none = kDone; a lane is free when it holds neither
+    uint64_t act = __ballot(cur != kDone || pend != kDone);
     const uint32_t nidle = 64u - (uint32_t)__popcll(act);
     if ((nidle >= (uint32_t)kRefillMin || act == 0) && (nbuf != 0 || more)) {
       while (nbuf == 0 && more) {
@@ -474,8 +484,8 @@ __device__ __forceinline__ void trace_wave(const DevScene& S, const Source& src,
         __builtin_amdgcn_wave_barrier();
       }
       if (nbuf != 0) {
-        const uint32_t r = lane_rank(~act);      // rank among the idle lanes
-        if (cur == kDone && r < nbuf) {
+        const uint32_t r = lane_rank(~act);      // rank among the free lanes
+        if (!((act >> lane) & 1ull) && r < nbuf) {
           const lds_u32* w = wbuf + (nbuf - 1u - r);
           o = v3(__uint_as_float(w[0]), __uint_as_float(w[64]), __uint_as_float(w[128]));
           d = v3(__uint_as_float(w[192]), __uint_as_float(w[256]), __uint_as_float(w[320]));
@@ -490,36 +500,41 @@ __device__ __forceinline__ void trace_wave(const DevScene& S, const Source& src,
         nbuf -= nidle < nbuf ? nidle : nbuf;
         __builtin_amdgcn_wave_barrier();
       }
-      act = __ballot(cur != kDone);
+      act = __ballot(cur != kDone || pend != kDone);
     }
     if (act == 0) break;                   // no ray in flight, nothing parked, nothing left to set up
 
-    const bool at_leaf = (int)cur < 0;
+    // Node phase: every lane at a node group steps.  Leaf phase: lanes holding a leaf test it --
+    // run only when enough lanes hold one (kDeferMin), enough lanes can do nothing else
+    // (kBlockMin), or no lane has node work.  In between a lane that reaches a leaf keeps it in
+    // `pend` and goes on with its next stack entry: the pending leaf's hit would have pruned a few
+    // of those steps (+2 % node steps, CPU replay in scripts/wave_replay.py), but the lane would
+    // have idled through them anyway, and closest hits do not depend on the order of the tests.
+    const bool alive = cur != kDone || pend != kDone;
     const bool at_node = cur < kDone;
-    const uint64_t leaf_mask = __ballot(at_leaf);
-    const bool any_node = (act & ~leaf_mask) != 0;
+    const bool has_pend = pend != kDone;
+    const bool want_leaf = has_pend || (int)cur < 0;
+    const uint64_t leaf_mask = __ballot(want_leaf);
+    const uint64_t node_mask = __ballot(at_node);
     bool pop = false;
     if (at_node) {
       pop = !node_step(S, stk, best.t * kPruneSlack, ivx, ivy, ivz, oix, oiy, oiz, &cur, &sp);
     }
-    if (leaf_mask != 0 && (!any_node || __popcll(leaf_mask) >= kDeferMin)) {
-      if (at_leaf) {
-        const uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
+    if (leaf_mask != 0 && (node_mask == 0 || __popcll(leaf_mask) >= kDeferMin || __popcll(leaf_mask & ~node_mask) >= kBlockMin)) {
+      if (want_leaf) {
+        const uint32_t leaf = has_pend ? pend : cur;
+        const uint32_t first = leaf & 0x0FFFFFFFu, cnt = (leaf >> 28) & 7u;
         for (uint32_t k = first; k < first + cnt; ++k) test_triangle(S, k, o, d, &best);
-        pop = true;
+        if (has_pend) pend = kDone; else pop = true;
         // tmax = 1.001 |light - P|: a hit below 0.998 tmax is before the light whatever the rounding
-        if (src.first_hit_decides() && best.id != -1 && best.t < 0.998f * src.tmax_of(slot)) sp = 0;
+        if (src.first_hit_decides() && best.id != -1 && best.t < 0.998f * src.tmax_of(slot)) { sp = 0; cur = kDone; pend = kDone; pop = false; }
       }
     }
+    if (RTX_SPEC != 0 && (RTX_SPEC == 1 || !src.first_hit_decides()) && (int)cur < 0 && pend == kDone) { pend = cur; pop = true; }
     if (pop) {
-      if (sp == 0) {
-        hits[slot] = make_uint2(__float_as_uint(best.id == -1 ? INFINITY : best.t), (uint32_t)best.id);
-        cur = kDone;
-      } else {
-        --sp;
-        cur = stk.pop(sp);
-      }
+      if (sp == 0) cur = kDone; else { --sp; cur = stk.pop(sp); }
     }
+    if (alive && cur == kDone && pend == kDone) hits[slot] = make_uint2(__float_as_uint(best.id == -1 ? INFINITY : best.t), (uint32_t)best.id);
   }
 }
 

@@ -1,0 +1,87 @@
+"""Wave-level replay on the CPU (no GPU needed): oracle/rt_oracle_bvh.c:ora_wave_sim walks the camera
+rays of sampled image regions the way one wave of trace_wave() would, under a scheduling policy
+(refill threshold, leaf deferral threshold, speculation past pending leaves), and counts the phases.
+
+    python3 scripts/wave_replay.py [workload] [nwaves]
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from oracle import oracle_api as oa  # noqa: E402
+from raytracing_project_amd import api, scenes  # noqa: E402
+
+CN, CL, CT, CS = 110.0, 12.0, 62.0, 150.0   # VALU instructions per node phase, leaf phase, triangle pass, setup round
+
+
+def replay(nodes, tris, order, lo, hi, o, d1, nwild, refill_min, defer_min, speculate, block_min=0):
+    n = len(o)
+    t = np.zeros(n, np.float32); f = np.zeros(n, np.int32); st = np.zeros(8, np.uint64)
+    u32 = C.POINTER(C.c_uint32)
+    fn = oa.lib().ora_wave_sim
+    fn.restype = None
+    fn.argtypes = [u32, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                   C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
+                   C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+    fn(nodes.ctypes.data_as(u32), oa.fp(tris), order.ctypes.data_as(C.POINTER(C.c_int32)), len(order), nwild, oa.fp(lo), oa.fp(hi),
+       oa.fp(o), oa.fp(d1), n, refill_min, defer_min, speculate, block_min, oa.fp(t), f.ctypes.data_as(C.POINTER(C.c_int32)),
+       st.ctypes.data_as(C.POINTER(C.c_uint64)))
+    return t, f, st.astype(np.float64)
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "soup1M_4k_primary_shadow"
+    nwaves = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    per_wave = 16
+    wl = bench.build_workload(name, api, scenes)
+    W, H = wl["W"], wl["H"]
+    scene = api.Scene(wl["verts"], wl["idx"], wl["tri_mat"], [api.make_material(**m) for m in wl["mats"]])
+    scene.build()
+    info = scene.info()
+    nodes, order = scene.bvh()
+    nodes = np.ascontiguousarray(nodes, np.uint32); order = np.ascontiguousarray(order, np.int32)
+    tris = np.ascontiguousarray(scene.tris(), np.float32)
+    _, osc = bench.oracle_scene(wl)
+    lo, hi = osc.root_box()
+    lo = np.ascontiguousarray(lo, np.float32); hi = np.ascontiguousarray(hi, np.float32)
+    ocam = oa.make_camera(wl["view"], W, H)
+    rng = np.random.RandomState(1)
+    policies = {"groups (64, no refill)": (64, 1, 0), "refill16 defer24 (tree)": (16, 24, 0), "refill16 defer1": (16, 1, 0)}
+    for d in (12, 16, 24):
+        policies["refill16 defer%d spec1" % d] = (16, d, 1)
+    for d in (16, 24, 32):
+        policies["refill16 defer%d spec2" % d] = (16, d, 2)
+    for d, b in ((24, 8), (32, 8), (32, 12), (40, 12), (64, 16), (64, 24)):
+        policies["refill16 defer%d block%d spec1" % (d, b)] = (16, d, 1, b)
+        policies["refill16 defer%d block%d spec2" % (d, b)] = (16, d, 2, b)
+    acc = {k: np.zeros(8) for k in policies}
+    for w in range(nwaves):
+        os_, ds_ = [], []
+        for g in range(per_wave):       # the wave's units: scattered 8x8 tiles (as the per-block lists are)
+            x0 = rng.randint(0, W // 8) * 8; y0 = rng.randint(0, H // 8) * 8
+            o, d1 = oa.camera_rays(ocam, (x0, y0, x0 + 8, y0 + 8))
+            os_.append(o); ds_.append(d1)
+        o = np.ascontiguousarray(np.concatenate(os_), np.float32); d1 = np.ascontiguousarray(np.concatenate(ds_), np.float32)
+        ref = None
+        for k, pol in policies.items():
+            t, f, st = replay(nodes, tris, order, lo, hi, o, d1, info.nwild, *pol)
+            if ref is None:
+                ref = (t, f)
+            assert np.array_equal(ref[0], t) and np.array_equal(ref[1], f), k
+            acc[k] += st
+    base = None
+    print("workload %s: %d waves x %d units" % (name, nwaves, per_wave))
+    for k, st in acc.items():
+        cost = st[0] * CN + st[2] * CL + st[3] * CT + st[5] * CS
+        base = base or cost
+        print("  %-34s cost %.3f  node phases %7d (util %.2f, %d steps)  leaf phases %6d  tri passes %6d (util %.2f)" % (
+            k, cost / base, st[0], st[1] / max(64 * st[0], 1), st[6], st[2], st[3], st[4] / max(64 * st[3], 1)))
+
+
+if __name__ == "__main__":
+    main()

@@ -17,7 +17,7 @@ import bench  # noqa: E402
 from oracle import oracle_api as oa  # noqa: E402
 from raytracing_project_amd import api, scenes  # noqa: E402
 
-CN, CL, CT = 64.0, 2.0, 58.0   # L1-return-path cycles: 4 loads per node-group step, ~3.6 per triangle (TD-bound model)
+CN, CL, CT = 110.0, 12.0, 62.0   # VALU instructions: ~110 per node-group step, ~62 per triangle test (ISA counts; the kernels are VALU-bound)
 
 
 def events(nodes, tris, order, lo, hi, o, d1, nwild, stride=1024):
