@@ -192,9 +192,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # setup, not steps: the library times both wave schedulers on its first three render calls of a
-    # scene and keeps the faster per launch kind; let that settle before the warmup / timed steps
-    for _ in range(3):
+    # setup, not steps: the library times its wave schedulers on its first four render calls of a
+    # scene and keeps the fastest per launch kind; let that settle before the warmup / timed steps
+    for _ in range(4):
         frame()
     for _ in range(args.warmup):
         frame()

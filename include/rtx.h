@@ -104,11 +104,15 @@ int rtx_scene_set_lights(rtx_scene*, const float* xyz, uint32_t n, const float* 
  * performs before its triangle scan, which gives Flyscene::intersectTriangle(faces, o, d)
  * semantics (src/flyscene.cpp:819-879) for a scene made of exactly that face list. */
 #define RTX_FLAG_NO_ROOT_GATE 1u
-/* RTX_FLAG_SCHED_REFILL / RTX_FLAG_SCHED_GROUPS: force one of the two wave schedulers of the
- * traversal kernels for every launch of this scene (default: chosen per launch; results are
- * identical either way).  No counterpart in the reference; for tests and tuning. */
+/* RTX_FLAG_SCHED_REFILL / RTX_FLAG_SCHED_GROUPS: force one of the wave schedulers of the
+ * traversal kernels for every launch of this scene (default: chosen per launch kind by timing
+ * them on the scene's first render calls; results are identical either way).
+ * RTX_FLAG_SCHED_SPLIT (only together with RTX_FLAG_SCHED_REFILL): the refilling scheduler's
+ * leaf phases stop when few lanes have triangles left and keep the rest of a leaf pending.
+ * No counterpart in the reference; for tests and tuning. */
 #define RTX_FLAG_SCHED_REFILL 2u
 #define RTX_FLAG_SCHED_GROUPS 4u
+#define RTX_FLAG_SCHED_SPLIT 8u
 int rtx_scene_set_flags(rtx_scene*, uint32_t flags);
 
 /* Flyscene::divideBox_KD + averagePoint / axisToDivide / isInBox and Box(mesh)

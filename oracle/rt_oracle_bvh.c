@@ -217,7 +217,7 @@ void ora_camera_rays(const ora_camera* cam, int x0, int y0, int x1, int y1, floa
  * `defer_min` lanes want one.  speculate != 0: a lane that reaches a leaf while the wave is not in
  * a leaf phase keeps the leaf in a pending slot (`speculate` of them, at most 4; a leaf phase tests the
  * oldest) and goes on with the next stack entry; block_min: a leaf phase also starts once that many lanes
- * can do nothing else (0 = off).
+ * can do nothing else (0 = off).  one_tri: a leaf phase tests one triangle per lane.
  * The hits must not depend on any of this (t/face are returned to check exactly that).
  * stats: [0] node phases, [1] lanes in them, [2] leaf phases, [3] triangle passes (sum of the
  * phase's largest leaf), [4] lane-triangles, [5] setup rounds, [6] node steps in total. */
@@ -255,7 +255,7 @@ static void ws_node_step(const bvh_job* j, ws_lane* L) {
 
 void ora_wave_sim(const uint32_t* nodes8, const float* tri16, const int32_t* tri_face, uint32_t ntris, uint32_t nwild,
                   const float* root_lo, const float* root_hi, const float* o, const float* d1, int n, int refill_min,
-                  int defer_min, int speculate, int block_min, float* t, int32_t* face, uint64_t* stats) {
+                  int defer_min, int speculate, int block_min, int one_tri, float* t, int32_t* face, uint64_t* stats) {
   bvh_job job; memset(&job, 0, sizeof job);
   job.nodes = nodes8; job.tris = tri16; job.tri_face = tri_face; job.ntris = ntris; job.nwild = nwild;
   static ws_lane lanes[64], parked[64];
@@ -305,6 +305,13 @@ void ora_wave_sim(const uint32_t* nodes8, const float* tri16, const int32_t* tri
         const int from_pend = L->npend != 0;
         const uint32_t leaf = from_pend ? L->pend[0] : L->cur;
         const uint32_t first = leaf & 0x0FFFFFFFu, cnt = (leaf >> 28) & 7u;
+        if (one_tri && cnt > 1) {   /* one triangle per lane and phase; the rest of the leaf stays where it is */
+          maxcnt = 1; stats[4] += 1;
+          tri_test(&job, first, L->o, L->d, &L->best_t, &L->best_id);
+          const uint32_t rest = LEAF_BIT | ((cnt - 1) << 28) | (first + 1);
+          if (from_pend) L->pend[0] = rest; else L->cur = rest;
+          continue;
+        }
         if (cnt > maxcnt) maxcnt = cnt;
         stats[4] += cnt;
         for (uint32_t k = first; k < first + cnt; ++k) tri_test(&job, k, L->o, L->d, &L->best_t, &L->best_id);

@@ -54,7 +54,7 @@ SYMBOLS = ["rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_
            "rtx_scene_get_leafboxes", "rtx_intersect_box", "rtx_trace_shade", "rtx_camera_points", "rtx_scene_set_flags",
            "rtx_scene_get_packed_bvh", "rtx_debug_hit"]
 
-FLAG_NO_ROOT_GATE, FLAG_SCHED_REFILL, FLAG_SCHED_GROUPS = 1, 2, 4
+FLAG_NO_ROOT_GATE, FLAG_SCHED_REFILL, FLAG_SCHED_GROUPS, FLAG_SCHED_SPLIT = 1, 2, 4, 8
 
 _lib = None
 

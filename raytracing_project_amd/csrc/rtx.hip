@@ -101,7 +101,7 @@ struct rtx_scene {
   // Scheduler tuning per launch kind (camera / shadow queue / bounce queue): the first frames of a
   // scene time both wave schedulers on the real work and keep the faster one (results are
   // identical either way, tests/test_gpu_parity.py).
-  struct Tune { int calls = 0; int choice = -1; double ms_per_ray[2] = {0, 0}; uint64_t rays_ref = 0; };
+  struct Tune { int calls = 0; int choice = -1; double ms_per_ray[3] = {0, 0, 0}; uint64_t rays_ref = 0; };
   Tune tune[3];
   std::vector<int> span_kind;        // kind of each trace span, -1 = not a scheduler-driven launch
   int cur_kind = -1;
@@ -173,8 +173,9 @@ extern "C" int rtx_scene_set_spheres(rtx_scene* s, const float* cr4, const int32
 
 extern "C" int rtx_scene_set_flags(rtx_scene* s, uint32_t flags) {
   if (!s) return fail(RTX_EINVAL, "null scene");
-  if (flags & ~(uint32_t)(RTX_FLAG_NO_ROOT_GATE | RTX_FLAG_SCHED_REFILL | RTX_FLAG_SCHED_GROUPS)) return fail(RTX_EINVAL, "unknown flag bits 0x%x", flags);
+  if (flags & ~(uint32_t)(RTX_FLAG_NO_ROOT_GATE | RTX_FLAG_SCHED_REFILL | RTX_FLAG_SCHED_GROUPS | RTX_FLAG_SCHED_SPLIT)) return fail(RTX_EINVAL, "unknown flag bits 0x%x", flags);
   if ((flags & RTX_FLAG_SCHED_REFILL) && (flags & RTX_FLAG_SCHED_GROUPS)) return fail(RTX_EINVAL, "pick one scheduler");
+  if ((flags & RTX_FLAG_SCHED_SPLIT) && !(flags & RTX_FLAG_SCHED_REFILL)) return fail(RTX_EINVAL, "RTX_FLAG_SCHED_SPLIT modifies RTX_FLAG_SCHED_REFILL");
   if ((flags ^ s->flags) & RTX_FLAG_NO_ROOT_GATE) s->committed = false;   // the scheduler bits are host-side only
   s->flags = flags;
   return RTX_OK;
@@ -597,36 +598,44 @@ static uint32_t grab_size() {
   }();
   return g;
 }
-// Scheduler per launch kind.  Order of precedence: RTX_FLAG_SCHED_* of the scene, the RTX_SCHED
-// environment variable ("refill" | "groups"), the tuned choice, the heuristic.
+// Scheduler per launch kind: SCHED_GROUPS, SCHED_REFILL (a leaf phase tests whole leaves) or
+// SCHED_REFILL_SPLIT (a leaf phase stops once fewer than kTriMinSplit lanes have triangles left; the
+// rest stays pending).  Order of precedence: RTX_FLAG_SCHED_* of the scene, the RTX_SCHED
+// environment variable ("refill" | "split" | "groups"), the tuned choice, the heuristic.
 enum { KIND_CAMERA = 0, KIND_SHADOW = 1, KIND_BOUNCE = 2 };
+enum { SCHED_GROUPS = 0, SCHED_REFILL = 1, SCHED_REFILL_SPLIT = 2 };
+constexpr uint32_t kTriMinSplit = 24;
 constexpr uint64_t kTuneMinRays = 200000;   // smaller launches are not worth timing
-static bool sched_heuristic(const rtx_scene* s, int kind, uint64_t rays) {
+static int sched_heuristic(const rtx_scene* s, int kind, uint64_t rays) {
   // Measured: the refilling scheduler wins on queued rays (shadow / bounce rays:
   // incoherent) and on camera rays once a wave has many 64-ray units to draw from (4K frames);
-  // group by group wins on the coherent camera rays of smaller frames.
-  if (kind != KIND_CAMERA) return true;
-  return rays >= (uint64_t)trace_grid(s) * (kBlock / 64) * 64 * 8;
+  // group by group wins on the coherent camera rays of smaller frames.  Split leaves win on
+  // triangle soups (few tests hit, nothing is lost by testing late) and lose on closed surfaces.
+  if (kind != KIND_CAMERA) return SCHED_REFILL;
+  return rays >= (uint64_t)trace_grid(s) * (kBlock / 64) * 64 * 8 ? SCHED_REFILL : SCHED_GROUPS;
 }
-static bool sched_refill(rtx_scene* s, int kind, uint64_t rays) {
+static int sched_forced() {
   static const int forced = [] {
     const char* e = std::getenv("RTX_SCHED");
     if (!e) return -1;
-    return std::strcmp(e, "refill") == 0 ? 1 : std::strcmp(e, "groups") == 0 ? 0 : -1;
+    return std::strcmp(e, "refill") == 0 ? SCHED_REFILL : std::strcmp(e, "split") == 0 ? SCHED_REFILL_SPLIT
+         : std::strcmp(e, "groups") == 0 ? SCHED_GROUPS : -1;
   }();
+  return forced;
+}
+static int sched_pick(rtx_scene* s, int kind, uint64_t rays) {
   if (!s->span_kind.empty()) s->span_kind.back() = kind;
-  if (s->flags & RTX_FLAG_SCHED_REFILL) return true;
-  if (s->flags & RTX_FLAG_SCHED_GROUPS) return false;
-  if (forced >= 0) return forced == 1;
+  if (s->flags & RTX_FLAG_SCHED_REFILL) return (s->flags & RTX_FLAG_SCHED_SPLIT) ? SCHED_REFILL_SPLIT : SCHED_REFILL;
+  if (s->flags & RTX_FLAG_SCHED_GROUPS) return SCHED_GROUPS;
+  if (sched_forced() >= 0) return sched_forced();
   const rtx_scene::Tune& T = s->tune[kind];
-  if (T.choice >= 0) return T.choice == 1;
-  if (T.calls == 1) return true;          // second call of this kind: time the refilling scheduler
-  if (T.calls == 2) return false;         // third: group by group
-  return sched_heuristic(s, kind, rays);  // first (cold caches: not timed)
+  if (T.choice >= 0) return T.choice;
+  if (T.calls >= 1 && T.calls <= 3) return T.calls - 1;   // calls 2-4 of this kind: time groups, refill, split
+  return sched_heuristic(s, kind, rays);                  // first (cold caches: not timed)
 }
 // After a render call: per kind, milliseconds per ray of this call's launches -> tuning state.
 static void tune_update(rtx_scene* s) {
-  if ((s->flags & (RTX_FLAG_SCHED_REFILL | RTX_FLAG_SCHED_GROUPS)) || std::getenv("RTX_SCHED")) return;
+  if ((s->flags & (RTX_FLAG_SCHED_REFILL | RTX_FLAG_SCHED_GROUPS)) || sched_forced() >= 0) return;
   double ms[3] = {0, 0, 0};
   bool seen[3] = {false, false, false};
   for (size_t i = 0; i < s->trace_spans.size() && i < s->span_kind.size(); ++i) {
@@ -643,13 +652,14 @@ static void tune_update(rtx_scene* s) {
     if (T.rays_ref && (rays[k] > 2 * T.rays_ref || 2 * rays[k] < T.rays_ref)) T = rtx_scene::Tune();   // another workload: start over
     if (T.choice >= 0) continue;
     if (T.calls == 0) T.rays_ref = rays[k];
-    if (T.calls == 1) T.ms_per_ray[1] = ms[k] / (double)rays[k];
-    if (T.calls == 2) {
-      T.ms_per_ray[0] = ms[k] / (double)rays[k];
-      const bool h = sched_heuristic(s, k, rays[k]);
-      // the heuristic's pick stays unless the other one is clearly (3 %) faster
-      const double mine = T.ms_per_ray[h ? 1 : 0], other = T.ms_per_ray[h ? 0 : 1];
-      T.choice = (other < 0.97 * mine) ? (h ? 0 : 1) : (h ? 1 : 0);
+    if (T.calls >= 1 && T.calls <= 3) T.ms_per_ray[T.calls - 1] = ms[k] / (double)rays[k];
+    if (T.calls == 3) {
+      // the heuristic's pick stays unless another one is clearly (3 %) faster
+      const int h = sched_heuristic(s, k, rays[k]);
+      int pick = h;
+      for (int c = 0; c < 3; ++c)
+        if (T.ms_per_ray[c] < 0.97 * T.ms_per_ray[h] && T.ms_per_ray[c] < T.ms_per_ray[pick]) pick = c;
+      T.choice = pick;
     }
     ++T.calls;
   }
@@ -657,11 +667,12 @@ static void tune_update(rtx_scene* s) {
 static int launch_trace_camera(rtx_scene* s, const DevCamera& C, uint32_t tiles, uint2* hits) {
   const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(tiles, 1), (uint32_t)trace_grid(s));
   const uint32_t grid_r = std::min<uint32_t>(grid, (uint32_t)s->ncu * RTX_BLOCKS_REFILL);
-  if (sched_refill(s, KIND_CAMERA, (uint64_t)tiles * kBlock))
+  const int mode = sched_pick(s, KIND_CAMERA, (uint64_t)tiles * kBlock);
+  if (mode != SCHED_GROUPS)
     hipLaunchKernelGGL(k_trace_camera<true>, dim3(grid_r), dim3(kBlock), 0, s->stream, s->dev, C, tiles, grab_size(),
-                       s->w_stack_ovf.as<uint32_t>(), hits);
+                       mode == SCHED_REFILL_SPLIT ? kTriMinSplit : 1u, s->w_stack_ovf.as<uint32_t>(), hits);
   else
-    hipLaunchKernelGGL(k_trace_camera<false>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, C, tiles, grab_size(),
+    hipLaunchKernelGGL(k_trace_camera<false>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, C, tiles, grab_size(), 1u,
                        s->w_stack_ovf.as<uint32_t>(), hits);
   return RTX_OK;
 }
@@ -670,11 +681,13 @@ static int launch_trace_queue(rtx_scene* s, const float4* rays, const uint32_t* 
   const uint64_t blocks = (bound * stride + kBlock - 1) / kBlock;
   const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, (uint64_t)trace_grid(s)));
   const uint32_t grid_r = std::min<uint32_t>(grid, (uint32_t)s->ncu * RTX_BLOCKS_REFILL);
-  if (sched_refill(s, shadow ? KIND_SHADOW : KIND_BOUNCE, bound * stride))
-    hipLaunchKernelGGL(k_trace_queue<true>, dim3(grid_r), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride, shadow ? (any_blocker ? 3u : 1u) : 0u, grab_size(),
-                       s->w_stack_ovf.as<uint32_t>(), hits);
+  const int mode = sched_pick(s, shadow ? KIND_SHADOW : KIND_BOUNCE, bound * stride);
+  const uint32_t bounded = shadow ? (any_blocker ? 3u : 1u) : 0u;
+  if (mode != SCHED_GROUPS)
+    hipLaunchKernelGGL(k_trace_queue<true>, dim3(grid_r), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride, bounded, grab_size(),
+                       mode == SCHED_REFILL_SPLIT ? kTriMinSplit : 1u, s->w_stack_ovf.as<uint32_t>(), hits);
   else
-    hipLaunchKernelGGL(k_trace_queue<false>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride, shadow ? (any_blocker ? 3u : 1u) : 0u, grab_size(),
+    hipLaunchKernelGGL(k_trace_queue<false>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride, bounded, grab_size(), 1u,
                        s->w_stack_ovf.as<uint32_t>(), hits);
   return RTX_OK;
 }

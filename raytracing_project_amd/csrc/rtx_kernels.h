@@ -425,7 +425,7 @@ constexpr int kWbufWords = 9;             // o.xyz, d.xyz, best.t, best.id, slot
 
 template <class Source>
 __device__ __forceinline__ void trace_wave(const DevScene& S, const Source& src, Work work, const Stack<kLdsStack>& stk, lds_u32* wbuf,
-                                           uint2* hits) {
+                                           uint32_t tri_min, uint2* hits) {
   const uint32_t lane = threadIdx.x & 63;
   uint32_t nbuf = 0;                       // parked rays (wave-uniform)
   uint32_t chunk = 0, chunk_end = 0;       // rest of the current grab (wave-uniform)
@@ -521,11 +521,19 @@ __device__ __forceinline__ void trace_wave(const DevScene& S, const Source& src,
       pop = !node_step(S, stk, best.t * kPruneSlack, ivx, ivy, ivz, oix, oiy, oiz, &cur, &sp);
     }
     if (leaf_mask != 0 && (node_mask == 0 || __popcll(leaf_mask) >= kDeferMin || __popcll(leaf_mask & ~node_mask) >= kBlockMin)) {
+      // One triangle per lane and pass; passes go on while at least tri_min lanes still have
+      // triangles of their leaf left (1: whole leaves).  What is left after that stays pending and
+      // the lane goes on with node work meanwhile: on a triangle soup, where few tests hit, the wave
+      // is not held for the biggest leaf (shadow kernel -5 %); on closed surfaces the late tests
+      // cost more pruning than they save (-2 to -7 %), so the host picks per scene and launch kind.
+      const uint32_t leaf = has_pend ? pend : cur;
+      uint32_t first = leaf & 0x0FFFFFFFu, cnt = want_leaf ? (leaf >> 28) & 7u : 0u;
+      do {
+        if (cnt != 0) { test_triangle(S, first, o, d, &best); ++first; --cnt; }
+      } while ((uint32_t)__popcll(__ballot(cnt != 0)) >= tri_min);
       if (want_leaf) {
-        const uint32_t leaf = has_pend ? pend : cur;
-        const uint32_t first = leaf & 0x0FFFFFFFu, cnt = (leaf >> 28) & 7u;
-        for (uint32_t k = first; k < first + cnt; ++k) test_triangle(S, k, o, d, &best);
-        if (has_pend) pend = kDone; else pop = true;
+        const uint32_t rest = cnt != 0 ? (0x80000000u | (cnt << 28) | first) : kDone;
+        if (has_pend) pend = rest; else if (cnt != 0) cur = rest; else pop = true;
         // tmax = 1.001 |light - P|: a hit below 0.998 tmax is before the light whatever the rounding
         if (src.first_hit_decides() && best.id != -1 && best.t < 0.998f * src.tmax_of(slot)) { sp = 0; cur = kDone; pend = kDone; pop = false; }
       }
@@ -595,7 +603,7 @@ __device__ __forceinline__ void trace_wave_groups(const DevScene& S, const Sourc
 // Camera rays of a pixel rectangle.  Ray index j = (16x16 pixel block, thread): consecutive
 // indices walk 8x8 pixel sub-tiles, so the 64 rays of a chunk are coherent.  Writes {t, id}.
 template <bool kRefill>
-__global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_trace_camera(DevScene S, DevCamera C, uint32_t nblocks, uint32_t grab, uint32_t* ovf,
+__global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_trace_camera(DevScene S, DevCamera C, uint32_t nblocks, uint32_t grab, uint32_t tri_min, uint32_t* ovf,
                                                           uint2* hits) {
   __shared__ uint32_t lds_stack[(kRefill ? kLdsStack : kLdsStackGroups) * kBlock];
   CameraSource src; src.C = C;
@@ -603,7 +611,7 @@ __global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_tra
   const Work work = make_work(nblocks * (uint32_t)kBlock, grab, &lds_ctr);
   if constexpr (kRefill) {
     __shared__ uint32_t lds_wbuf[(kBlock / 64) * kWbufWords * 64];
-    trace_wave(S, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), hits);
+    trace_wave(S, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), tri_min, hits);
   } else {
     trace_wave_groups(S, src, work, make_stack<kLdsStackGroups>(lds_stack, ovf), hits);
   }
@@ -612,14 +620,14 @@ __global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_tra
 // Queued rays: rays[2i] = {o.xyz, aux}, rays[2i+1] = {d1.xyz, aux}; *count * stride rays.
 template <bool kRefill>
 __global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_trace_queue(DevScene S, const float4* rays, const uint32_t* count, uint32_t stride,
-                                                         uint32_t bounded, uint32_t grab, uint32_t* ovf, uint2* hits) {
+                                                         uint32_t bounded, uint32_t grab, uint32_t tri_min, uint32_t* ovf, uint2* hits) {
   __shared__ uint32_t lds_stack[(kRefill ? kLdsStack : kLdsStackGroups) * kBlock];
   QueueSource src; src.rays = rays; src.bounded = bounded; src.anyhit = ((bounded & 2u) && (S.flags & 2u)) ? 1u : 0u;
   __shared__ uint32_t lds_ctr;
   const Work work = make_work(*count * stride, grab, &lds_ctr);
   if constexpr (kRefill) {
     __shared__ uint32_t lds_wbuf[(kBlock / 64) * kWbufWords * 64];
-    trace_wave(S, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), hits);
+    trace_wave(S, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), tri_min, hits);
   } else {
     trace_wave_groups(S, src, work, make_stack<kLdsStackGroups>(lds_stack, ovf), hits);
   }

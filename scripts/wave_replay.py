@@ -19,17 +19,17 @@ from raytracing_project_amd import api, scenes  # noqa: E402
 CN, CL, CT, CS = 110.0, 12.0, 62.0, 150.0   # VALU instructions per node phase, leaf phase, triangle pass, setup round
 
 
-def replay(nodes, tris, order, lo, hi, o, d1, nwild, refill_min, defer_min, speculate, block_min=0):
+def replay(nodes, tris, order, lo, hi, o, d1, nwild, refill_min, defer_min, speculate, block_min=0, one_tri=0):
     n = len(o)
     t = np.zeros(n, np.float32); f = np.zeros(n, np.int32); st = np.zeros(8, np.uint64)
     u32 = C.POINTER(C.c_uint32)
     fn = oa.lib().ora_wave_sim
     fn.restype = None
     fn.argtypes = [u32, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float),
-                   C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
+                   C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                    C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
     fn(nodes.ctypes.data_as(u32), oa.fp(tris), order.ctypes.data_as(C.POINTER(C.c_int32)), len(order), nwild, oa.fp(lo), oa.fp(hi),
-       oa.fp(o), oa.fp(d1), n, refill_min, defer_min, speculate, block_min, oa.fp(t), f.ctypes.data_as(C.POINTER(C.c_int32)),
+       oa.fp(o), oa.fp(d1), n, refill_min, defer_min, speculate, block_min, one_tri, oa.fp(t), f.ctypes.data_as(C.POINTER(C.c_int32)),
        st.ctypes.data_as(C.POINTER(C.c_uint64)))
     return t, f, st.astype(np.float64)
 
@@ -51,14 +51,12 @@ def main():
     lo = np.ascontiguousarray(lo, np.float32); hi = np.ascontiguousarray(hi, np.float32)
     ocam = oa.make_camera(wl["view"], W, H)
     rng = np.random.RandomState(1)
-    policies = {"groups (64, no refill)": (64, 1, 0), "refill16 defer24 (tree)": (16, 24, 0), "refill16 defer1": (16, 1, 0)}
-    for d in (12, 16, 24):
-        policies["refill16 defer%d spec1" % d] = (16, d, 1)
-    for d in (16, 24, 32):
-        policies["refill16 defer%d spec2" % d] = (16, d, 2)
-    for d, b in ((24, 8), (32, 8), (32, 12), (40, 12), (64, 16), (64, 24)):
-        policies["refill16 defer%d block%d spec1" % (d, b)] = (16, d, 1, b)
-        policies["refill16 defer%d block%d spec2" % (d, b)] = (16, d, 2, b)
+    policies = {"groups (64, no refill)": (64, 1, 0), "refill16 defer24 (before)": (16, 24, 0), "refill16 defer1": (16, 1, 0)}
+    policies["refill16 defer24 block8 spec1 (tree)"] = (16, 24, 1, 8)
+    policies["refill16 defer32 block8 spec2"] = (16, 32, 2, 8)
+    for d, b in ((24, 8), (32, 8), (32, 12), (40, 16)):
+        for sp in (1, 2):
+            policies["refill16 defer%d block%d spec%d one-tri" % (d, b, sp)] = (16, d, sp, b, 1)
     acc = {k: np.zeros(8) for k in policies}
     for w in range(nwaves):
         os_, ds_ = [], []
@@ -79,7 +77,7 @@ def main():
     for k, st in acc.items():
         cost = st[0] * CN + st[2] * CL + st[3] * CT + st[5] * CS
         base = base or cost
-        print("  %-34s cost %.3f  node phases %7d (util %.2f, %d steps)  leaf phases %6d  tri passes %6d (util %.2f)" % (
+        print("  %-40s cost %.3f  node phases %7d (util %.2f, %d steps)  leaf phases %6d  tri passes %6d (util %.2f)" % (
             k, cost / base, st[0], st[1] / max(64 * st[0], 1), st[6], st[2], st[3], st[4] / max(64 * st[3], 1)))
 
 

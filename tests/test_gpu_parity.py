@@ -396,8 +396,8 @@ def test_camera_points_vs_reference_golden(api):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["dodgeColorTest", "twoObjects"])
 def test_both_wave_schedulers_give_identical_frames(api, name):
-    """The traversal kernels have two wave schedulers (lane refill with parked rays / group by
-    group); the library picks one per launch.  Forced either way (RTX_FLAG_SCHED_*), every
+    """The traversal kernels have two wave schedulers (lane refill with parked rays -- with whole
+    or split leaf phases -- / group by group); the library picks one per launch.  Forced each way (RTX_FLAG_SCHED_*), every
     output of a frame -- face ids, t, RGB of the full reflect + refract + GI pipeline -- must be
     bit-identical, and equal to the oracle's dump."""
     fx = load_scene_fixture(name)
@@ -408,15 +408,18 @@ def test_both_wave_schedulers_give_identical_frames(api, name):
     res = int(fx["res"])
     opts = api.Options(*REF_OPTS) if leaves else ns_options(api)
     out = {}
-    for flag in (api.FLAG_SCHED_REFILL, api.FLAG_SCHED_GROUPS, 0):
+    split = api.FLAG_SCHED_REFILL | api.FLAG_SCHED_SPLIT
+    for flag in (api.FLAG_SCHED_REFILL, api.FLAG_SCHED_GROUPS, split, 0):
         s.set_flags(flag)
         frames = []
         for cname in CAMS:
             cam = api.make_camera(fx["view_" + cname], res, res)
             frames.append(s.render(cam, opts, (0, 0, res, res)))
         out[flag] = frames
-    for cname, a, b, c in zip(CAMS, out[api.FLAG_SCHED_REFILL], out[api.FLAG_SCHED_GROUPS], out[0]):
-        assert np.array_equal(a[2], b[2]) and np.array_equal(a[2], c[2])
+    for cname, a, b, c, e in zip(CAMS, out[api.FLAG_SCHED_REFILL], out[api.FLAG_SCHED_GROUPS], out[0], out[split]):
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[2], c[2]) and np.array_equal(a[2], e[2])
+        assert_bits_equal(a[1], e[1], "t refill vs split")
+        assert_bits_equal(a[0], e[0], "rgb refill vs split")
         assert_bits_equal(a[1], b[1], "t refill vs groups")
         assert_bits_equal(a[0], b[0], "rgb refill vs groups")
         assert_bits_equal(a[0], c[0], "rgb refill vs default")
@@ -447,6 +450,11 @@ def test_refill_scheduler_camera_kernel_on_a_large_frame(api, oa):
     assert np.array_equal(f_a, f_b)
     assert_bits_equal(t_a, t_b, "t")
     assert_bits_equal(rgb_a, rgb_b, "rgb")
+    s.set_flags(api.FLAG_SCHED_REFILL | api.FLAG_SCHED_SPLIT)
+    rgb_c, t_c, f_c = s.render(cam, opts, (0, 0, W, H))
+    assert np.array_equal(f_a, f_c)
+    assert_bits_equal(t_a, t_c, "t (split leaves)")
+    assert_bits_equal(rgb_a, rgb_c, "rgb (split leaves)")
     omat = oa.make_mtl(ka=(0, 0, 0), kd=(.7, .7, .7), ks=(.2, .2, .2), ns=10, d=1.0)
     o = oa.Scene(verts, idx, np.zeros(len(idx), np.int32), [omat])
     ocam = oa.make_camera(view, W, H)
