@@ -192,9 +192,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # setup, not steps: the library times its wave schedulers on its first four render calls of a
+    # setup, not steps: the library times its wave schedulers on its first seven render calls of a
     # scene and keeps the fastest per launch kind; let that settle before the warmup / timed steps
-    for _ in range(4):
+    for _ in range(7):
         frame()
     for _ in range(args.warmup):
         frame()

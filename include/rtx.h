@@ -106,7 +106,7 @@ int rtx_scene_set_lights(rtx_scene*, const float* xyz, uint32_t n, const float* 
 #define RTX_FLAG_NO_ROOT_GATE 1u
 /* RTX_FLAG_SCHED_REFILL / RTX_FLAG_SCHED_GROUPS: force one of the wave schedulers of the
  * traversal kernels for every launch of this scene (default: chosen per launch kind by timing
- * them on the scene's first render calls; results are identical either way).
+ * them on the scene's first seven render calls; results are identical either way).
  * RTX_FLAG_SCHED_SPLIT (only together with RTX_FLAG_SCHED_REFILL): the refilling scheduler's
  * leaf phases stop when few lanes have triangles left and keep the rest of a leaf pending.
  * No counterpart in the reference; for tests and tuning. */

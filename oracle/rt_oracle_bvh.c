@@ -226,6 +226,8 @@ typedef struct {
   float o[3], d[3], iv[3], oi[3], best_t; int best_id; uint32_t cur, pend[4]; int npend; uint32_t stack[96]; int sp; int ray;
 } ws_lane;
 
+static int g_ws_sort = 5;   /* compare-exchanges of the child sort (study: 3 = only the nearest is exact) */
+void ora_wave_sim_sort(int n) { g_ws_sort = n; }
 static void ws_node_step(const bvh_job* j, ws_lane* L) {
   const uint32_t* q = j->nodes + 32 * (size_t)L->cur;
   float lim = L->best_t * PRUNE_SLACK, tn[4];
@@ -241,7 +243,7 @@ static void ws_node_step(const bvh_job* j, ws_lane* L) {
     en[k] = c ? (LEAF_BIT | (c << 28) | ref) : ref;
   }
 #define CX(a, b) do { if (tn[b] < tn[a]) { float tf_ = tn[a]; tn[a] = tn[b]; tn[b] = tf_; uint32_t te_ = en[a]; en[a] = en[b]; en[b] = te_; } } while (0)
-  CX(0, 1); CX(2, 3); CX(0, 2); CX(1, 3); CX(1, 2);
+  CX(0, 1); CX(2, 3); CX(0, 2); if (g_ws_sort > 3) CX(1, 3); if (g_ws_sort > 4) CX(1, 2);
 #undef CX
   if (tn[0] != INFINITY) {
     if (tn[3] != INFINITY) L->stack[L->sp++] = en[3];

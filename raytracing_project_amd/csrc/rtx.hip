@@ -630,7 +630,7 @@ static int sched_pick(rtx_scene* s, int kind, uint64_t rays) {
   if (sched_forced() >= 0) return sched_forced();
   const rtx_scene::Tune& T = s->tune[kind];
   if (T.choice >= 0) return T.choice;
-  if (T.calls >= 1 && T.calls <= 3) return T.calls - 1;   // calls 2-4 of this kind: time groups, refill, split
+  if (T.calls >= 1 && T.calls <= 2 * 3) return (T.calls - 1) % 3;   // calls 2-7 of this kind: time groups, refill, split, twice each
   return sched_heuristic(s, kind, rays);                  // first (cold caches: not timed)
 }
 // After a render call: per kind, milliseconds per ray of this call's launches -> tuning state.
@@ -652,14 +652,18 @@ static void tune_update(rtx_scene* s) {
     if (T.rays_ref && (rays[k] > 2 * T.rays_ref || 2 * rays[k] < T.rays_ref)) T = rtx_scene::Tune();   // another workload: start over
     if (T.choice >= 0) continue;
     if (T.calls == 0) T.rays_ref = rays[k];
-    if (T.calls >= 1 && T.calls <= 3) T.ms_per_ray[T.calls - 1] = ms[k] / (double)rays[k];
-    if (T.calls == 3) {
-      // the heuristic's pick stays unless another one is clearly (3 %) faster
+    if (T.calls >= 1 && T.calls <= 2 * 3) T.ms_per_ray[(T.calls - 1) % 3] += ms[k] / (double)rays[k];
+    if (T.calls == 2 * 3) {
+      // the heuristic's pick stays unless another one is clearly (2 %, over two frames each) faster
       const int h = sched_heuristic(s, k, rays[k]);
       int pick = h;
       for (int c = 0; c < 3; ++c)
-        if (T.ms_per_ray[c] < 0.97 * T.ms_per_ray[h] && T.ms_per_ray[c] < T.ms_per_ray[pick]) pick = c;
+        if (T.ms_per_ray[c] < 0.98 * T.ms_per_ray[h] && T.ms_per_ray[c] < T.ms_per_ray[pick]) pick = c;
       T.choice = pick;
+      static const bool log = std::getenv("RTX_TUNE_LOG") != nullptr;
+      if (log)
+        std::fprintf(stderr, "[rtx] scheduler for launch kind %d (%llu rays): groups %.3g, refill %.3g, split %.3g ns/ray -> %d\n", k,
+                     (unsigned long long)rays[k], 5e5 * T.ms_per_ray[0], 5e5 * T.ms_per_ray[1], 5e5 * T.ms_per_ray[2], pick);
     }
     ++T.calls;
   }

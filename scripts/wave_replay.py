@@ -37,7 +37,7 @@ def replay(nodes, tris, order, lo, hi, o, d1, nwild, refill_min, defer_min, spec
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "soup1M_4k_primary_shadow"
     nwaves = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-    per_wave = 16
+    per_wave = int(sys.argv[3]) if len(sys.argv) > 3 else 16   # 64-ray units per wave (the GPU: ~18 at 4K)
     wl = bench.build_workload(name, api, scenes)
     W, H = wl["W"], wl["H"]
     scene = api.Scene(wl["verts"], wl["idx"], wl["tri_mat"], [api.make_material(**m) for m in wl["mats"]])
@@ -53,10 +53,7 @@ def main():
     rng = np.random.RandomState(1)
     policies = {"groups (64, no refill)": (64, 1, 0), "refill16 defer24 (before)": (16, 24, 0), "refill16 defer1": (16, 1, 0)}
     policies["refill16 defer24 block8 spec1 (tree)"] = (16, 24, 1, 8)
-    policies["refill16 defer32 block8 spec2"] = (16, 32, 2, 8)
-    for d, b in ((24, 8), (32, 8), (32, 12), (40, 16)):
-        for sp in (1, 2):
-            policies["refill16 defer%d block%d spec%d one-tri" % (d, b, sp)] = (16, d, sp, b, 1)
+    policies["refill16 defer24 block8 spec1 one-tri (tree, split)"] = (16, 24, 1, 8, 1)
     acc = {k: np.zeros(8) for k in policies}
     for w in range(nwaves):
         os_, ds_ = [], []
@@ -77,8 +74,8 @@ def main():
     for k, st in acc.items():
         cost = st[0] * CN + st[2] * CL + st[3] * CT + st[5] * CS
         base = base or cost
-        print("  %-40s cost %.3f  node phases %7d (util %.2f, %d steps)  leaf phases %6d  tri passes %6d (util %.2f)" % (
-            k, cost / base, st[0], st[1] / max(64 * st[0], 1), st[6], st[2], st[3], st[4] / max(64 * st[3], 1)))
+        print("  %-52s cost %.3f (%.0f per ray)  node phases %7d (util %.2f, %d steps)  leaf phases %6d  tri passes %6d (util %.2f)" % (
+            k, cost / base, cost / (nwaves * per_wave * 64), st[0], st[1] / max(64 * st[0], 1), st[6], st[2], st[3], st[4] / max(64 * st[3], 1)))
 
 
 if __name__ == "__main__":
