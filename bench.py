@@ -316,7 +316,7 @@ def roofline(args, wl, scene, info, ms, rays):
         res["achieved_layout_bytes"] = prim_layout_bytes * spp / (kms * 1e-3) / 1e9
         res["frac_layout_bytes"] = res["achieved_layout_bytes"] / HBM_PEAK_GBS
         res["note"] = ("both figures are load demand, not HBM traffic: the scene is cache resident (see traffic), "
-                       "so frac may exceed 1; the kernel's real bound is the L1 return path (DESIGN.md 5)")
+                       "so frac may exceed 1; the kernel's real bound is vector-ALU issue (84 % busy, profiles/r01_soup1M_4k_final.txt; DESIGN.md 5)")
     # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this
     # process, so the figure comes from the committed rocprofv3 --pmc passes of this same
     # command (profiles/r01_traffic.json, corrected as MI355X_MICROARCH.md prescribes).

@@ -7,7 +7,8 @@
  *      (algorithmic bytes = 32*nodes_visited + 36*tris_tested + io).
  * It mirrors closest_hit() of raytracing_project_amd/csrc/rtx_kernels.h step by step
  * (same near-first order, same culling slab arithmetic, same prune slack), so the counts
- * are those of the GPU's own traversal order.  Triangle acceptance is the reference test
+ * are those of the GPU's own traversal order for a ray walked on its own (the refilling scheduler's
+ * pending leaves add ~2 % node steps on top, see ora_wave_sim below).  Triangle acceptance is the reference test
  * (src/Intersect.cpp:6-46) on the hoisted per-triangle constants.
  */
 #include <math.h>
@@ -122,7 +123,7 @@ static void* bvh_worker(void* arg) {
             en[k] = c ? (LEAF_BIT | (c << 28) | ref) : ref;
           }
 #define CX(a, b) do { if (tn[b] < tn[a]) { float tf_ = tn[a]; tn[a] = tn[b]; tn[b] = tf_; uint32_t te_ = en[a]; en[a] = en[b]; en[b] = te_; } } while (0)
-          CX(0, 1); CX(2, 3); CX(0, 2); CX(1, 3); CX(1, 2);
+          CX(0, 1); CX(2, 3); CX(0, 2); CX(1, 3);   /* as node_step(): the two middle children stay unordered (RTX_SORT_CX 4) */
 #undef CX
           if (tn[0] != INFINITY) {
             if (tn[3] != INFINITY) stack[sp++] = en[3];
@@ -226,7 +227,7 @@ typedef struct {
   float o[3], d[3], iv[3], oi[3], best_t; int best_id; uint32_t cur, pend[4]; int npend; uint32_t stack[96]; int sp; int ray;
 } ws_lane;
 
-static int g_ws_sort = 5;   /* compare-exchanges of the child sort (study: 3 = only the nearest is exact) */
+static int g_ws_sort = 4;   /* compare-exchanges of the child sort (study: 3 = only the nearest is exact) */
 void ora_wave_sim_sort(int n) { g_ws_sort = n; }
 static void ws_node_step(const bvh_job* j, ws_lane* L) {
   const uint32_t* q = j->nodes + 32 * (size_t)L->cur;

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Derived figures from the text summaries scripts/prof_summary.py writes (no GPU, no sqlite needed).
+
+    scripts/prof_derive.py <summary.txt>... [--traffic-json workload]
+
+Per traversal kernel: VALU busy share of the kernel's cycles, active lanes per VALU instruction,
+resident waves per SIMD, TA / TD busy, L2 hit rate, HBM-side bytes per launch (FETCH_SIZE doubled as
+MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE).  With --traffic-json the per-kernel
+traffic is printed as the JSON object bench.py reads from profiles/r01_traffic.json.
+"""
+import json
+import re
+import sys
+
+NSIMD, NCU, NSE, NXCD = 1024, 256, 32, 8
+
+
+def load(files):
+    d = {}
+    for fn in files:
+        for line in open(fn):
+            m = re.match(r"(.{50}) (\S+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s*$", line)
+            if m:
+                kern = re.sub(r"^void ", "", m.group(1).strip())
+                kern = re.sub(r"^rtx::", "", kern).split("(")[0]
+                d[(kern, m.group(2))] = float(m.group(5))
+    return d
+
+
+def main():
+    args = sys.argv[1:]
+    want_json = None
+    if "--traffic-json" in args:
+        i = args.index("--traffic-json")
+        want_json = args[i + 1]
+        del args[i:i + 2]
+    d = load(args)
+    kernels = sorted({k for k, _ in d if k.startswith("k_")})
+    if want_json:
+        out = {}
+        for k in kernels:
+            f, w = d.get((k, "FETCH_SIZE")), d.get((k, "WRITE_SIZE"))
+            if f is None or w is None:
+                continue
+            name = k.split("<")[0]
+            if name in out and "<false>" in k:
+                continue
+            out[name] = {"fetch_kb_raw": f, "write_kb_raw": w, "hbm_bytes_per_launch": (2 * f + w) * 1024}
+        print(json.dumps({want_json: out}, indent=1))
+        return
+    print("== derived (scripts/prof_derive.py; per launch) ==")
+    for k in kernels:
+        g = lambda c: d.get((k, c))  # noqa: E731
+        if g("SQ_BUSY_CYCLES") is None or g("SQ_INSTS_VALU") is None:
+            continue
+        busy = g("SQ_BUSY_CYCLES") / NSE          # cycles the kernel kept a shader engine busy
+        line = "%-24s VALU insts %.4g, VALU busy %.1f %% of SIMD cycles" % (k[:24], g("SQ_INSTS_VALU"), 400.0 * g("SQ_ACTIVE_INST_VALU") / (NSIMD * busy))
+        if g("SQ_THREAD_CYCLES_VALU"):
+            line += ", active lanes %.1f %%" % (100.0 * g("SQ_THREAD_CYCLES_VALU") / (64 * g("SQ_INSTS_VALU")))
+        if g("SQ_WAVE_CYCLES"):
+            line += ", waves/SIMD %.2f" % (4.0 * g("SQ_WAVE_CYCLES") / (NSIMD * busy))
+        if g("TA_TA_BUSY_sum") and g("GRBM_GUI_ACTIVE"):
+            cyc = g("GRBM_GUI_ACTIVE") / NXCD
+            line += ", TA busy %.0f %%, TD busy %.0f %%" % (100 * g("TA_TA_BUSY_sum") / (NCU * cyc), 100 * g("TD_TD_BUSY_sum") / (NCU * cyc))
+        if g("TCC_REQ_sum"):
+            line += ", L2 hit %.0f %%" % (100 * g("TCC_HIT_sum") / g("TCC_REQ_sum"))
+        if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+            line += ", HBM-side bytes %.3g" % ((2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024)
+        print(line)
+
+
+if __name__ == "__main__":
+    main()
