@@ -12,6 +12,11 @@
  * Threading: calls on one rtx_scene are serialised by the caller; different scenes are
  * independent (one HIP stream each).  The reference mutates its scene only between
  * renders (src/main.cpp:63-77); so does this API (mutators need a new rtx_scene_commit).
+ *
+ * Limits (RTX_ELIMIT beyond them): fewer than 2^28 triangles; fewer than 2^31 pixels per call
+ * and fewer than 2^31 rays per query call and per ray generation of a render (pixels x light
+ * samples, or x 2^bounces with reflection and refraction both on); max_bounces <= 16 (8 for
+ * reflection + refraction trees); gi_rays <= 64.
  */
 #ifndef RTX_H
 #define RTX_H

@@ -875,7 +875,8 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
   const bool any_child = opt->reflection || opt->refraction;
   const int max_gen = (shade && any_child) ? std::max(0, opt->max_bounces - pr.bounce0) : 0;
   const uint64_t max_nodes = tree ? ((uint64_t)pr.n0 << max_gen) : pr.n0;
-  if (max_nodes * std::max<uint64_t>(std::max(NLS, G), 1) >= (1ull << 32)) return fail(RTX_ELIMIT, "ray queue would exceed 2^32 entries");
+  // ray indices are 32-bit in the kernels and a wave's next unit may lie up to one grid of units past the end
+  if (max_nodes * std::max<uint64_t>(std::max(NLS, G), 1) >= (1ull << 31)) return fail(RTX_ELIMIT, "ray queue would exceed 2^31 entries");
   if (int rc = s->w_hits[0].ensure((size_t)pr.n0 * 8)) return rc;
   if (shade) {
     if (int rc = s->w_parents.ensure((size_t)max_nodes * 4)) return rc;
