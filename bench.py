@@ -106,13 +106,22 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with that many ranks" % args.gpus)
+    # RTX_BENCH_REHEARSE=1: all ranks share GPU 0 and exchange over gloo through host memory -- a dry run
+    # of the N > 1 control flow on a one-GPU box (RCCL refuses two ranks on one device).  Its line says
+    # so ("rehearsal": true) and is not a measurement.
+    rehearse = world > 1 and os.environ.get("RTX_BENCH_REHEARSE") == "1"
     dist = None
+    if rehearse:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -140,7 +149,7 @@ def main():
              "face": torch.full((npix_local, 1), -1, dtype=torch.int32, device=dev),
              "free": torch.cuda.Event()}
         b["acc"] = torch.zeros_like(b["rgb"]) if len(cams) > 1 else None
-        if world > 1 and rank == 0:
+        if world > 1 and rank == 0 and not rehearse:
             b["g_rgb"] = torch.empty((world, npix_local, 3), dtype=torch.float32, device=dev)
             b["g_face"] = torch.empty((world, npix_local, 1), dtype=torch.int32, device=dev)
         b["free"].record()
@@ -175,9 +184,15 @@ def main():
             if acc is not None:
                 acc.add_(rgb)
         out = rgb if acc is None else acc.mul_(1.0 / len(cams))
-        if world > 1:
+        if rehearse:
+            g_rgb = tiles.gather_to_root(out.cpu(), world, rank, dist)
+            g_face = tiles.gather_to_root(face.cpu(), world, rank, dist)
+            if rank == 0:
+                g_rgb, g_face = g_rgb.to(dev), g_face.to(dev)
+        elif world > 1:
             g_rgb = tiles.gather_to_root(out, world, rank, dist, b.get("g_rgb"))
             g_face = tiles.gather_to_root(face, world, rank, dist, b.get("g_face"))
+        if world > 1:
             img = None
             if rank == 0:
                 img = (tiles.assemble(g_rgb, W, H, TILE, 3), tiles.assemble(g_face, W, H, TILE, 1))
@@ -209,8 +224,8 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     # whole-job aggregates: rays summed over ranks, time = max over ranks
-    agg = torch.tensor([float(rays_tot[0]), float(rays_tot[1]), float(rays_tot[2])], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    agg = torch.tensor([float(rays_tot[0]), float(rays_tot[1]), float(rays_tot[2])], dtype=torch.float64, device="cpu" if rehearse else dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
     if dist is not None:
         dist.all_reduce(agg)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -235,6 +250,14 @@ def main():
                                                       "trace_queue": ms_tot[1] / args.steps,
                                                       "all_kernels": ms_tot[2] / args.steps}},
         }
+    if rank == 0 and rehearse:
+        result["config"]["rehearsal"] = True
+        if len(cams) == 1:      # the reassembled parts against one full-frame render, bit for bit
+            f_rgb = torch.zeros((W * H, 3), dtype=torch.float32, device=dev)
+            f_face = torch.full((W * H, 1), -1, dtype=torch.int32, device=dev)
+            scene.render_dev(cams[0], opts, rect, f_rgb.data_ptr(), None, f_face.data_ptr())
+            result["config"]["rehearsal_equals_full_frame"] = bool(
+                torch.equal(img[1].reshape(-1), f_face.reshape(-1)) and torch.equal(img[0].reshape(-1, 3).view(torch.int32), f_rgb.view(torch.int32)))
     if rank == 0 and world == 1 and not args.no_roofline:
         result["roofline"] = roofline(args, wl, scene, info, ms_tot / args.steps, rays_tot / args.steps)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
