@@ -92,7 +92,9 @@ struct rtx_scene {
   DevBuf d_nodes, d_tris, d_tri_face, d_face_nm, d_spheres, d_sph_mat, d_mats, d_lights;
   DevBuf d_slights, d_leafboxes, d_leaf_faces, d_face_pos;
   // workspace
-  DevBuf w_cam_tab;                  // per-call camera tables (k_camera_tables)
+  DevBuf w_cam_tab;                  // camera tables (k_camera_tables)
+  DevCamera cam_tab_of{};            // the camera w_cam_tab currently holds the tables of (valid: cam_tab_ok)
+  bool cam_tab_ok = false;
   DevBuf w_stack_ovf;                // global overflow columns of the per-lane traversal stacks
   DevBuf w_rays[2], w_hits[2], w_parents, w_shadow_rays, w_shadow_hits, w_gi_rays, w_gi_hits, w_counters, w_io[6];
   EventPool events;
@@ -144,6 +146,7 @@ static void release_device(rtx_scene* s) {
                     &s->w_shadow_rays, &s->w_shadow_hits, &s->w_counters, &s->w_io[0], &s->w_io[1], &s->w_io[2],
                     &s->w_io[3], &s->w_io[4], &s->w_io[5]};
   for (DevBuf* b : bufs) b->release();
+  s->cam_tab_ok = false;
   s->events.release();
   if (s->stream) { (void)hipStreamDestroy(s->stream); s->stream = nullptr; }
   s->committed = false;
@@ -829,7 +832,7 @@ extern "C" int rtx_render_dev(rtx_scene* s, const rtx_camera* cam, const rtx_opt
                               float* t, int32_t* face) {
   if (int rc = check_ready(s)) return rc;
   if (int rc = check_render_args(s, cam, opt, rgb)) return rc;
-  DevCamera C;
+  DevCamera C{};
   if (int rc = make_camera(cam, rect, &C)) return rc;
   const uint32_t npix = (uint32_t)C.w * (uint32_t)C.h;
   const uint32_t tiles = (uint32_t)((C.w + 15) / 16) * (uint32_t)((C.h + 15) / 16);
@@ -851,7 +854,7 @@ extern "C" int rtx_render_tiles_dev(rtx_scene* s, const rtx_camera* cam, const r
   if (int rc = check_render_args(s, cam, opt, rgb)) return rc;
   const int nt = rtx_tiles_count(rect, tile_size, part, nparts);
   if (nt < 0) return nt;
-  DevCamera C;
+  DevCamera C{};
   if (int rc = make_camera(cam, rect, &C)) return rc;
   if (nt == 0) return RTX_OK;
   if ((int64_t)nt * tile_size * tile_size >= (1ll << 31)) return fail(RTX_ELIMIT, "too many pixels in this part");
@@ -898,8 +901,8 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
   if (int rc = s->w_counters.ensure((size_t)(max_gen + 2) * 16 + 16)) return rc;
   HIP_TRY(hipMemsetAsync(s->w_counters.p, 0, (size_t)(max_gen + 2) * 16, s->stream));
   uint32_t* cnt = s->w_counters.as<uint32_t>();
-  uint32_t* n0_dev = cnt + (size_t)(max_gen + 2) * 4;       // device copy of n0 for the queue kernels
-  HIP_TRY(hipMemcpyAsync(n0_dev, &pr.n0, 4, hipMemcpyHostToDevice, s->stream));
+  uint32_t* n0_dev = cnt + (size_t)(max_gen + 2) * 4;       // device copy of n0 for the queue kernel of caller rays
+  if (!pr.camera) HIP_TRY(hipMemcpyAsync(n0_dev, &pr.n0, 4, hipMemcpyHostToDevice, s->stream));
 
   span_begin(s, true);
   if (pr.camera) {
@@ -967,10 +970,16 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
 static int render_impl(rtx_scene* s, const DevCamera& C, uint32_t npix, uint32_t tiles, const rtx_options* opt,
                        float* rgb, float* t, int32_t* face) {
   stats_begin(s);
+  const size_t tab_cap = s->w_cam_tab.cap;
   if (int rc = s->w_cam_tab.ensure((size_t)(C.w + C.h) * 4)) return rc;
+  if (s->w_cam_tab.cap != tab_cap) s->cam_tab_ok = false;      // a new allocation (maybe at the old address)
   Primary pr; pr.camera = true; pr.C = C; pr.n0 = npix; pr.tiles = tiles; pr.bounce0 = 0;
   pr.C.tab = s->w_cam_tab.as<float>();
-  hipLaunchKernelGGL(k_camera_tables, dim3((uint32_t)(C.w + C.h + 255) / 256), dim3(256), 0, s->stream, pr.C, s->w_cam_tab.as<float>());
+  // the tables depend on the camera and the rectangle only: frames of one camera reuse them
+  if (!s->cam_tab_ok || std::memcmp(&s->cam_tab_of, &pr.C, sizeof(DevCamera)) != 0) {
+    hipLaunchKernelGGL(k_camera_tables, dim3((uint32_t)(C.w + C.h + 255) / 256), dim3(256), 0, s->stream, pr.C, s->w_cam_tab.as<float>());
+    s->cam_tab_of = pr.C; s->cam_tab_ok = true;
+  }
   if (int rc = run_pipeline(s, pr, opt, rgb, t, face)) return rc;
   uint64_t live = npix;
   if (C.ts) {   // partial edge tiles: count only slots that are pixels of the rectangle
