@@ -201,6 +201,39 @@ def main():
         b["free"].record()
         return rays, ms, img
 
+    # One rank, one sample per pixel: frames go through rtx_render_dev_enqueue / rtx_render_finish, frame
+    # k+1 queued before frame k is waited for, so the GPU does not idle while the host finishes a frame.
+    pipelined = world == 1 and len(cams) == 1
+
+    def frame_enqueue():
+        b = sets[state["k"] % NSETS]
+        state["k"] += 1
+        b["free"].synchronize()
+        scene.render_dev_enqueue(cams[0], opts, rect, b["rgb"].data_ptr(), None, b["face"].data_ptr())
+        return b
+
+    def frame_finish(b):
+        st = scene.render_finish()
+        rays = [st.rays_primary, st.rays_shadow, st.rays_reflection]
+        ms = [st.ms_trace_camera, st.ms_trace - st.ms_trace_camera, st.ms_total]
+        b["free"].record()
+        return rays, ms, (b["rgb"].view(H, W, 3), b["face"].view(H, W, 1))
+
+    def frames(n):
+        """n frames; returns the per-frame (rays, ms, img) tuples."""
+        out = []
+        if not pipelined:
+            return [frame() for _ in range(n)]
+        prev = None
+        for _ in range(n):
+            b = frame_enqueue()
+            if prev is not None:
+                out.append(frame_finish(prev))
+            prev = b
+        if prev is not None:
+            out.append(frame_finish(prev))
+        return out
+
     def sync():
         torch.cuda.synchronize()
         if dist is not None:
@@ -209,16 +242,14 @@ def main():
 
     # setup, not steps: the library times its wave schedulers on its first seven render calls of a
     # scene and keeps the fastest per launch kind; let that settle before the warmup / timed steps
-    for _ in range(7):
-        frame()
-    for _ in range(args.warmup):
-        frame()
+    frames(7)
+    frames(args.warmup)
     sync()
     t0 = time.perf_counter()
     rays_tot = np.zeros(3, np.int64)
     ms_tot = np.zeros(3, np.float64)
-    for _ in range(args.steps):
-        r, m, img = frame()
+    img = None
+    for r, m, img in frames(args.steps):
         rays_tot += r
         ms_tot += m
     sync()
@@ -242,7 +273,7 @@ def main():
             "config": {"workload": args.workload, "triangles": int(info.ntris), "bvh_nodes": int(info.nnodes),
                        "image": [W, H], "lights": len(wl["lights"]), "spp": wl["spp"], "max_bounces": wl["opts"][0],
                        "tile": TILE, "partition": ("image tiles round-robin over %d ranks, scene replicated, gather to rank 0" % world) if world > 1
-                       else "one rank renders the whole frame row-major",
+                       else "one rank renders the whole frame row-major" + (", two frames in flight (rtx_render_dev_enqueue)" if pipelined else ""),
                        "rays_per_frame": {"primary": int(agg[0].item() / args.steps), "shadow": int(agg[1].item() / args.steps),
                                           "reflection": int(agg[2].item() / args.steps)},
                        "pixels_hitting_geometry": hits,

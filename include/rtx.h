@@ -206,6 +206,18 @@ int rtx_render(rtx_scene*, const rtx_camera*, const rtx_options*, rtx_rect rect,
                float* rgb, float* t, int32_t* face_id);
 int rtx_render_dev(rtx_scene*, const rtx_camera*, const rtx_options*, rtx_rect rect,
                    float* rgb, float* t, int32_t* face_id);
+/* rtx_render_dev in two halves, for sequences of frames: rtx_render_dev_enqueue queues the call's
+ * kernels on the scene's stream and returns; rtx_render_finish waits for the oldest call enqueued
+ * and not yet finished and reports its statistics (stats may be NULL; RTX_ESTATE when there is
+ * none).  Two calls may be in flight: enqueue frame k+1, then finish frame k, and the GPU never
+ * idles between frames.  Calls run in the order they were enqueued (the scene's workspace is
+ * shared), the outputs of a call are complete once it is finished, a third enqueue first
+ * finishes the oldest call, and any other entry point on the scene finishes all of them.
+ * No counterpart in the reference (raytraceScene returns when the frame is done,
+ * src/flyscene.cpp:395-468). */
+int rtx_render_dev_enqueue(rtx_scene*, const rtx_camera*, const rtx_options*, rtx_rect rect,
+                           float* rgb, float* t, int32_t* face_id);
+int rtx_render_finish(rtx_scene*, rtx_stats* stats);
 
 /* The row-strided thread decomposition of raytraceScene (src/flyscene.cpp:418-430,460) as an
  * image-tile partition for several GPUs: `rect` is cut into tile_size x tile_size tiles

@@ -49,7 +49,7 @@ SYMBOLS = ["rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_
            "rtx_scene_add_material", "rtx_scene_set_spheres", "rtx_scene_set_lights", "rtx_scene_build", "rtx_scene_commit",
            "rtx_scene_get_tris",
            "rtx_scene_get_info", "rtx_scene_get_bvh", "rtx_trace_closest", "rtx_trace_closest_dev",
-           "rtx_trace_visible", "rtx_render", "rtx_render_dev", "rtx_tiles_count", "rtx_render_tiles_dev",
+           "rtx_trace_visible", "rtx_render", "rtx_render_dev", "rtx_render_dev_enqueue", "rtx_render_finish", "rtx_tiles_count", "rtx_render_tiles_dev",
            "rtx_get_stats", "rtx_scene_build_reference_leafboxes", "rtx_scene_set_leafboxes",
            "rtx_scene_get_leafboxes", "rtx_intersect_box", "rtx_trace_shade", "rtx_camera_points", "rtx_scene_set_flags",
            "rtx_scene_get_packed_bvh", "rtx_debug_hit"]
@@ -88,6 +88,9 @@ def lib():
         L.rtx_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Options), Rect, _f, _f, _i]
         L.rtx_render_dev.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Options), Rect, C.c_void_p,
                                      C.c_void_p, C.c_void_p]
+        L.rtx_render_dev_enqueue.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Options), Rect, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]
+        L.rtx_render_finish.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.rtx_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.rtx_scene_build_reference_leafboxes.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
         L.rtx_scene_set_leafboxes.argtypes = [C.c_void_p, _f, _f, _u, _u, C.c_uint32, _i, C.c_uint32]
@@ -306,6 +309,18 @@ class Scene:
         x0, y0, x1, y1 = rect
         _check(lib().rtx_render_dev(self.h, C.byref(cam), C.byref(opts), Rect(x0, y0, x1, y1), rgb_ptr, t_ptr,
                                     face_ptr))
+
+    def render_dev_enqueue(self, cam, opts, rect, rgb_ptr, t_ptr, face_ptr):
+        """render_dev without the wait; pair every call with render_finish() (two may be in flight)."""
+        x0, y0, x1, y1 = rect
+        _check(lib().rtx_render_dev_enqueue(self.h, C.byref(cam), C.byref(opts), Rect(x0, y0, x1, y1), rgb_ptr, t_ptr,
+                                            face_ptr))
+
+    def render_finish(self):
+        """Waits for the oldest enqueued render call; returns its Stats."""
+        s = Stats()
+        _check(lib().rtx_render_finish(self.h, C.byref(s)))
+        return s
 
     def render_tiles_dev(self, cam, opts, rect, tile_size, part, nparts, rgb_ptr, t_ptr, face_ptr):
         x0, y0, x1, y1 = rect

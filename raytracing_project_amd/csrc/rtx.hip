@@ -97,21 +97,43 @@ struct rtx_scene {
   bool cam_tab_ok = false;
   DevBuf w_stack_ovf;                // global overflow columns of the per-lane traversal stacks
   DevBuf w_rays[2], w_hits[2], w_parents, w_shadow_rays, w_shadow_hits, w_gi_rays, w_gi_hits, w_counters, w_io[6];
-  EventPool events;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_spans, all_spans;
-  size_t camera_span = (size_t)-1;   // index into trace_spans of the k_trace_camera launch
-  // Scheduler tuning per launch kind (camera / shadow queue / bounce queue): the first frames of a
-  // scene time both wave schedulers on the real work and keep the faster one (results are
-  // identical either way, tests/test_gpu_parity.py).
-  struct Tune { int calls = 0; int choice = -1; double ms_per_ray[3] = {0, 0, 0}; uint64_t rays_ref = 0; };
+  // Per-call bookkeeping.  Two of them, so that a render call can be enqueued while the one before is
+  // still running (rtx_render_dev_enqueue / rtx_render_finish); every other entry point begins and
+  // finishes its call in one go.
+  struct Call {
+    EventPool events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_spans, all_spans;
+    size_t camera_span = (size_t)-1;   // index into trace_spans of the k_trace_camera launch
+    std::vector<int> span_kind;        // kind of each trace span, -1 = not a scheduler-driven launch
+    int mode[3] = {-1, -1, -1};        // scheduler mode of this call per launch kind (-1: none picked yet)
+    bool timed[3] = {false, false, false};   // ... and whether that pick is one of the tuner's trials
+    uint32_t* hc = nullptr;            // pinned host copy of the pipeline's counters
+    size_t hc_words = 0;
+    bool pending = false;              // enqueued, not finished yet
+    bool pipeline = false, shade = false, shadows = false, tune = false;   // what finish_call has to account for
+    int max_gen = 0;
+    uint32_t NLS = 0, G = 0;
+    rtx_stats stats{};
+  };
+  Call calls[2];
+  int cur = 0;
+  // Scheduler tuning per launch kind (camera / shadow queue / bounce queue): after a first untimed
+  // call, the next calls of a scene run the scheduler modes in turn on the real work, twice each, and
+  // the fastest is kept (results are identical whichever runs, tests/test_gpu_parity.py).
+  struct Tune {
+    bool started = false, too_small = false;
+    int choice = -1;
+    int launched[3] = {0, 0, 0}, done[3] = {0, 0, 0};
+    double ms_per_ray[3] = {0, 0, 0};
+    uint64_t rays_ref = 0;
+  };
   Tune tune[3];
-  std::vector<int> span_kind;        // kind of each trace span, -1 = not a scheduler-driven launch
-  int cur_kind = -1;
-  rtx_stats stats{};
+  rtx_stats stats{};                   // of the last finished call
   rtx_scene_info info{};
   int ncu = 256;
 };
 
+static rtx_scene::Call& cur_call(rtx_scene* s) { return s->calls[s->cur]; }
 static int trace_grid(const rtx_scene* s) { return s->ncu * 8; }      // 8 blocks x 4 waves = 32 waves per CU
 
 extern "C" const char* rtx_last_error(void) { return g_err.c_str(); }
@@ -145,9 +167,14 @@ static void release_device(rtx_scene* s) {
                     &s->w_gi_hits, &s->w_stack_ovf, &s->w_cam_tab, &s->w_rays[0], &s->w_rays[1], &s->w_hits[0], &s->w_hits[1], &s->w_parents,
                     &s->w_shadow_rays, &s->w_shadow_hits, &s->w_counters, &s->w_io[0], &s->w_io[1], &s->w_io[2],
                     &s->w_io[3], &s->w_io[4], &s->w_io[5]};
+  if (s->stream) (void)hipStreamSynchronize(s->stream);      // calls still in flight
   for (DevBuf* b : bufs) b->release();
   s->cam_tab_ok = false;
-  s->events.release();
+  for (rtx_scene::Call& c : s->calls) {
+    c.events.release();
+    if (c.hc) (void)hipHostFree(c.hc);
+    c.hc = nullptr; c.hc_words = 0; c.pending = false;
+  }
   if (s->stream) { (void)hipStreamDestroy(s->stream); s->stream = nullptr; }
   s->committed = false;
 }
@@ -552,37 +579,71 @@ static int grid_for(const rtx_scene* s, size_t items) {
   return (int)std::max<size_t>(1, std::min(blocks, cap));
 }
 static void span_begin(rtx_scene* s, bool trace) {
-  hipEvent_t a = s->events.get(), b = s->events.get();
+  rtx_scene::Call& c = cur_call(s);
+  hipEvent_t a = c.events.get(), b = c.events.get();
   (void)hipEventRecord(a, s->stream);
-  (trace ? s->trace_spans : s->all_spans).push_back({a, b});
-  if (trace) { s->span_kind.push_back(-1); s->cur_kind = -1; }
+  (trace ? c.trace_spans : c.all_spans).push_back({a, b});
+  if (trace) c.span_kind.push_back(-1);
 }
 static void span_end(rtx_scene* s, bool trace) {
-  (void)hipEventRecord((trace ? s->trace_spans : s->all_spans).back().second, s->stream);
+  rtx_scene::Call& c = cur_call(s);
+  (void)hipEventRecord((trace ? c.trace_spans : c.all_spans).back().second, s->stream);
 }
-static void stats_begin(rtx_scene* s) {
-  s->events.reset(); s->trace_spans.clear(); s->all_spans.clear(); s->camera_span = (size_t)-1;
-  s->span_kind.clear();
-  std::memset(&s->stats, 0, sizeof s->stats);
-  span_begin(s, false);
-}
-static int stats_end(rtx_scene* s) {
-  span_end(s, false);
-  HIP_TRY(hipStreamSynchronize(s->stream));
+static void tune_update(rtx_scene* s, rtx_scene::Call& c);
+// Waits for an enqueued call, turns its events and counters into rtx_stats, feeds the tuner.
+static int finish_call(rtx_scene* s, rtx_scene::Call& c) {
+  if (!c.pending) return RTX_OK;
+  c.pending = false;
+  HIP_TRY(hipEventSynchronize(c.all_spans[0].second));
   HIP_TRY(hipGetLastError());
   float ms = 0;
-  for (size_t i = 0; i < s->trace_spans.size(); ++i) {
+  for (size_t i = 0; i < c.trace_spans.size(); ++i) {
     float m = 0;
-    (void)hipEventElapsedTime(&m, s->trace_spans[i].first, s->trace_spans[i].second);
+    (void)hipEventElapsedTime(&m, c.trace_spans[i].first, c.trace_spans[i].second);
     ms += m;
-    if (i == s->camera_span) s->stats.ms_trace_camera = m;
+    if (i == c.camera_span) c.stats.ms_trace_camera = m;
   }
-  s->stats.ms_trace = ms;
-  s->stats.launches_trace = (uint32_t)s->trace_spans.size();
+  c.stats.ms_trace = ms;
+  c.stats.launches_trace = (uint32_t)c.trace_spans.size();
   float tot = 0;
-  (void)hipEventElapsedTime(&tot, s->all_spans[0].first, s->all_spans[0].second);
-  s->stats.ms_total = tot;
+  (void)hipEventElapsedTime(&tot, c.all_spans[0].first, c.all_spans[0].second);
+  c.stats.ms_total = tot;
+  if (c.pipeline && c.shade) {
+    const uint32_t* hc = c.hc;
+    for (int g = 0; g <= c.max_gen; ++g) {
+      if (c.shadows) c.stats.rays_shadow += (uint64_t)hc[4 * g] * c.NLS;
+      c.stats.rays_gi += (uint64_t)hc[4 * g] * c.G;
+      if (g < c.max_gen) { c.stats.rays_refraction += hc[4 * g + 2]; c.stats.rays_reflection += hc[4 * g + 1] - hc[4 * g + 2]; }
+    }
+  }
+  if (c.tune) tune_update(s, c);
+  s->stats = c.stats;
   return RTX_OK;
+}
+// Every call starts here: takes the call slot that is not the most recent one (finishing what it
+// still holds) and opens the span of the whole call.
+static int stats_begin(rtx_scene* s) {
+  s->cur ^= 1;
+  rtx_scene::Call& c = cur_call(s);
+  if (int rc = finish_call(s, c)) return rc;
+  c.events.reset(); c.trace_spans.clear(); c.all_spans.clear(); c.camera_span = (size_t)-1;
+  c.span_kind.clear();
+  for (int k = 0; k < 3; ++k) { c.mode[k] = -1; c.timed[k] = false; }
+  c.pipeline = c.shade = c.shadows = c.tune = false; c.max_gen = 0; c.NLS = c.G = 0;
+  std::memset(&c.stats, 0, sizeof c.stats);
+  span_begin(s, false);
+  return RTX_OK;
+}
+// ... and ends here: closes the span; the call is now in flight.
+static void stats_enqueue_end(rtx_scene* s) {
+  span_end(s, false);
+  cur_call(s).pending = true;
+}
+// The synchronous form: every call in flight is finished, oldest first.
+static int stats_end(rtx_scene* s) {
+  stats_enqueue_end(s);
+  if (int rc = finish_call(s, s->calls[s->cur ^ 1])) return rc;
+  return finish_call(s, cur_call(s));
 }
 static int check_ready(rtx_scene* s) {
   if (!s) return fail(RTX_EINVAL, "null scene");
@@ -627,48 +688,69 @@ static int sched_forced() {
   return forced;
 }
 static int sched_pick(rtx_scene* s, int kind, uint64_t rays) {
-  if (!s->span_kind.empty()) s->span_kind.back() = kind;
+  rtx_scene::Call& c = cur_call(s);
+  if (!c.span_kind.empty()) c.span_kind.back() = kind;
   if (s->flags & RTX_FLAG_SCHED_REFILL) return (s->flags & RTX_FLAG_SCHED_SPLIT) ? SCHED_REFILL_SPLIT : SCHED_REFILL;
   if (s->flags & RTX_FLAG_SCHED_GROUPS) return SCHED_GROUPS;
   if (sched_forced() >= 0) return sched_forced();
-  const rtx_scene::Tune& T = s->tune[kind];
-  if (T.choice >= 0) return T.choice;
-  if (T.calls >= 1 && T.calls <= 2 * 3) return (T.calls - 1) % 3;   // calls 2-7 of this kind: time groups, refill, split, twice each
-  return sched_heuristic(s, kind, rays);                  // first (cold caches: not timed)
+  if (c.mode[kind] >= 0) return c.mode[kind];          // one mode per kind and call
+  rtx_scene::Tune& T = s->tune[kind];
+  int m;
+  if (T.choice >= 0) m = T.choice;
+  else if (!T.started || T.too_small) { m = sched_heuristic(s, kind, rays); T.started = true; }   // first call (cold caches) and small launches: not timed
+  else {
+    m = 0;                                              // the mode tried least so far: groups, refill, split, twice each
+    for (int k = 1; k < 3; ++k) if (T.launched[k] < T.launched[m]) m = k;
+    ++T.launched[m];
+    c.timed[kind] = true;
+  }
+  c.mode[kind] = m;
+  return m;
 }
-// After a render call: per kind, milliseconds per ray of this call's launches -> tuning state.
-static void tune_update(rtx_scene* s) {
+// When a render call has finished: per kind, milliseconds per ray of its launches -> tuning state.
+static void tune_update(rtx_scene* s, rtx_scene::Call& c) {
   if ((s->flags & (RTX_FLAG_SCHED_REFILL | RTX_FLAG_SCHED_GROUPS)) || sched_forced() >= 0) return;
   double ms[3] = {0, 0, 0};
   bool seen[3] = {false, false, false};
-  for (size_t i = 0; i < s->trace_spans.size() && i < s->span_kind.size(); ++i) {
-    const int k = s->span_kind[i];
+  for (size_t i = 0; i < c.trace_spans.size() && i < c.span_kind.size(); ++i) {
+    const int k = c.span_kind[i];
     if (k < 0) continue;
     float m = 0;
-    (void)hipEventElapsedTime(&m, s->trace_spans[i].first, s->trace_spans[i].second);
+    (void)hipEventElapsedTime(&m, c.trace_spans[i].first, c.trace_spans[i].second);
     ms[k] += m; seen[k] = true;
   }
-  const uint64_t rays[3] = {s->stats.rays_primary, s->stats.rays_shadow, s->stats.rays_reflection + s->stats.rays_refraction};
+  const uint64_t rays[3] = {c.stats.rays_primary, c.stats.rays_shadow, c.stats.rays_reflection + c.stats.rays_refraction};
   for (int k = 0; k < 3; ++k) {
     rtx_scene::Tune& T = s->tune[k];
-    if (!seen[k] || rays[k] < kTuneMinRays) continue;
-    if (T.rays_ref && (rays[k] > 2 * T.rays_ref || 2 * rays[k] < T.rays_ref)) T = rtx_scene::Tune();   // another workload: start over
+    if (!seen[k] || rays[k] == 0) continue;
+    if (T.rays_ref && (rays[k] > 2 * T.rays_ref || 2 * rays[k] < T.rays_ref)) { T = rtx_scene::Tune(); T.started = true; }   // another workload: start over
     if (T.choice >= 0) continue;
-    if (T.calls == 0) T.rays_ref = rays[k];
-    if (T.calls >= 1 && T.calls <= 2 * 3) T.ms_per_ray[(T.calls - 1) % 3] += ms[k] / (double)rays[k];
-    if (T.calls == 2 * 3) {
-      // the heuristic's pick stays unless another one is clearly (2 %, over two frames each) faster
+    if (T.rays_ref == 0) T.rays_ref = rays[k];
+    const int m = c.mode[k];
+    if (rays[k] < kTuneMinRays) {                       // not worth timing: the heuristic from now on
+      T.too_small = true;
+      if (c.timed[k] && m >= 0 && T.launched[m] > 0) --T.launched[m];
+      continue;
+    }
+    T.too_small = false;
+    if (!c.timed[k] || m < 0) continue;
+    // the better of a mode's trials counts: the first launch of a kernel variant also pays for loading it
+    const double per_ray = ms[k] / (double)rays[k];
+    T.ms_per_ray[m] = T.done[m] ? std::min(T.ms_per_ray[m], per_ray) : per_ray;
+    ++T.done[m];
+    if (T.done[0] >= 2 && T.done[1] >= 2 && T.done[2] >= 2) {
+      // the heuristic's pick stays unless another one is clearly (2 %) faster
       const int h = sched_heuristic(s, k, rays[k]);
+      const double* per = T.ms_per_ray;
       int pick = h;
-      for (int c = 0; c < 3; ++c)
-        if (T.ms_per_ray[c] < 0.98 * T.ms_per_ray[h] && T.ms_per_ray[c] < T.ms_per_ray[pick]) pick = c;
+      for (int q = 0; q < 3; ++q)
+        if (per[q] < 0.98 * per[h] && per[q] < per[pick]) pick = q;
       T.choice = pick;
       static const bool log = std::getenv("RTX_TUNE_LOG") != nullptr;
       if (log)
         std::fprintf(stderr, "[rtx] scheduler for launch kind %d (%llu rays): groups %.3g, refill %.3g, split %.3g ns/ray -> %d\n", k,
-                     (unsigned long long)rays[k], 5e5 * T.ms_per_ray[0], 5e5 * T.ms_per_ray[1], 5e5 * T.ms_per_ray[2], pick);
+                     (unsigned long long)rays[k], 1e6 * per[0], 1e6 * per[1], 1e6 * per[2], pick);
     }
-    ++T.calls;
   }
 }
 static int launch_trace_camera(rtx_scene* s, const DevCamera& C, uint32_t tiles, uint2* hits) {
@@ -716,11 +798,11 @@ extern "C" int rtx_trace_closest_dev(rtx_scene* s, const float* o, const float* 
   if (int rc = check_ready(s)) return rc;
   if (n == 0) return RTX_OK;
   if (!o || !d) return fail(RTX_EINVAL, "null ray arrays");
-  stats_begin(s);
+  if (int rc = stats_begin(s)) return rc;
   if (int rc = trace_rays_dev(s, o, d, n)) return rc;
   hipLaunchKernelGGL(k_unpack_hits, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->dev, s->w_rays[0].as<float4>(),
                      s->w_hits[0].as<uint2>(), n, t, face, (float*)nullptr, (float*)nullptr, (int*)nullptr);
-  s->stats.rays_primary = n;
+  cur_call(s).stats.rays_primary = n;
   return stats_end(s);
 }
 
@@ -738,13 +820,13 @@ extern "C" int rtx_trace_closest(rtx_scene* s, const float* o, const float* d, u
   if (int rc = s->w_io[5].ensure(b1)) return rc;
   HIP_TRY(hipMemcpyAsync(s->w_io[0].p, o, b3, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipMemcpyAsync(s->w_io[1].p, d, b3, hipMemcpyHostToDevice, s->stream));
-  stats_begin(s);
+  if (int rc = stats_begin(s)) return rc;
   if (int rc = trace_rays_dev(s, s->w_io[0].as<float>(), s->w_io[1].as<float>(), n)) return rc;
   float* d_n = s->w_io[4].as<float>();
   float* d_p = d_n + (size_t)n * 3;
   hipLaunchKernelGGL(k_unpack_hits, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->dev, s->w_rays[0].as<float4>(),
                      s->w_hits[0].as<uint2>(), n, s->w_io[2].as<float>(), s->w_io[3].as<int>(), d_n, d_p, s->w_io[5].as<int>());
-  s->stats.rays_primary = n;
+  cur_call(s).stats.rays_primary = n;
   if (int rc = stats_end(s)) return rc;
   if (t) HIP_TRY(hipMemcpy(t, s->w_io[2].p, b1, hipMemcpyDeviceToHost));
   if (face) HIP_TRY(hipMemcpy(face, s->w_io[3].p, b1, hipMemcpyDeviceToHost));
@@ -770,7 +852,7 @@ extern "C" int rtx_trace_visible(rtx_scene* s, const float* light, const float* 
   HIP_TRY(hipMemcpyAsync(s->w_io[0].p, light, b3, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipMemcpyAsync(s->w_io[1].p, pos, b3, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipMemcpyAsync(s->w_counters.p, &n, 4, hipMemcpyHostToDevice, s->stream));
-  stats_begin(s);
+  if (int rc = stats_begin(s)) return rc;
   hipLaunchKernelGGL(k_make_shadow_rays, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->w_io[0].as<float>(),
                      s->w_io[1].as<float>(), n, s->w_rays[0].as<float4>());
   span_begin(s, true);
@@ -778,7 +860,7 @@ extern "C" int rtx_trace_visible(rtx_scene* s, const float* light, const float* 
   span_end(s, true);
   hipLaunchKernelGGL(k_visible, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->dev, s->w_io[0].as<float>(),
                      s->w_rays[0].as<float4>(), s->w_hits[0].as<uint2>(), n, s->w_io[2].as<unsigned char>(), s->w_io[3].as<int>());
-  s->stats.rays_shadow = n;
+  cur_call(s).stats.rays_shadow = n;
   if (int rc = stats_end(s)) return rc;
   HIP_TRY(hipMemcpy(visible, s->w_io[2].p, n, hipMemcpyDeviceToHost));
   if (bmat) HIP_TRY(hipMemcpy(bmat, s->w_io[3].p, (size_t)n * 4, hipMemcpyDeviceToHost));
@@ -814,7 +896,7 @@ static int make_camera(const rtx_camera* cam, rtx_rect r, DevCamera* C) {
 }
 
 static int render_impl(rtx_scene* s, const DevCamera& C, uint32_t npix, uint32_t nblocks, const rtx_options* opt,
-                       float* rgb, float* t, int32_t* face);
+                       float* rgb, float* t, int32_t* face, bool wait = true);
 static int check_render_args(rtx_scene* s, const rtx_camera* cam, const rtx_options* opt, const float* rgb);
 
 static int check_render_args(rtx_scene* s, const rtx_camera* cam, const rtx_options* opt, const float* rgb) {
@@ -837,6 +919,28 @@ extern "C" int rtx_render_dev(rtx_scene* s, const rtx_camera* cam, const rtx_opt
   const uint32_t npix = (uint32_t)C.w * (uint32_t)C.h;
   const uint32_t tiles = (uint32_t)((C.w + 15) / 16) * (uint32_t)((C.h + 15) / 16);
   return render_impl(s, C, npix, tiles, opt, rgb, t, face);
+}
+
+// rtx_render_dev without the wait at the end: the call's kernels are queued on the scene's stream and
+// the function returns.  rtx_render_finish waits for the oldest such call and reports its statistics.
+extern "C" int rtx_render_dev_enqueue(rtx_scene* s, const rtx_camera* cam, const rtx_options* opt, rtx_rect rect, float* rgb,
+                                      float* t, int32_t* face) {
+  if (int rc = check_ready(s)) return rc;
+  if (int rc = check_render_args(s, cam, opt, rgb)) return rc;
+  DevCamera C{};
+  if (int rc = make_camera(cam, rect, &C)) return rc;
+  const uint32_t npix = (uint32_t)C.w * (uint32_t)C.h;
+  const uint32_t tiles = (uint32_t)((C.w + 15) / 16) * (uint32_t)((C.h + 15) / 16);
+  return render_impl(s, C, npix, tiles, opt, rgb, t, face, false);
+}
+extern "C" int rtx_render_finish(rtx_scene* s, rtx_stats* out) {
+  if (int rc = check_ready(s)) return rc;
+  rtx_scene::Call& older = s->calls[s->cur ^ 1];
+  rtx_scene::Call& c = older.pending ? older : cur_call(s);
+  if (!c.pending) return fail(RTX_ESTATE, "no enqueued render call to finish");
+  if (int rc = finish_call(s, c)) return rc;
+  if (out) *out = c.stats;
+  return RTX_OK;
 }
 
 extern "C" int rtx_tiles_count(rtx_rect rect, int32_t tile_size, int32_t part, int32_t nparts) {
@@ -906,7 +1010,7 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
 
   span_begin(s, true);
   if (pr.camera) {
-    s->camera_span = s->trace_spans.size() - 1;
+    cur_call(s).camera_span = cur_call(s).trace_spans.size() - 1;
     if (int rc = launch_trace_camera(s, pr.C, pr.tiles, s->w_hits[0].as<uint2>())) return rc;
   } else {
     if (int rc = launch_trace_queue(s, s->w_rays[0].as<float4>(), n0_dev, 1u, pr.n0, s->w_hits[0].as<uint2>())) return rc;
@@ -954,22 +1058,23 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
       span_end(s, true);
     }
   }
-  std::vector<uint32_t> hc((size_t)(max_gen + 2) * 4);
-  HIP_TRY(hipMemcpyAsync(hc.data(), s->w_counters.p, hc.size() * 4, hipMemcpyDeviceToHost, s->stream));
-  if (int rc = stats_end(s)) return rc;
-  if (shade) {
-    for (int g = 0; g <= max_gen; ++g) {
-      if (opt->shadows) s->stats.rays_shadow += (uint64_t)hc[4 * g] * NLS;
-      s->stats.rays_gi += (uint64_t)hc[4 * g] * G;
-      if (g < max_gen) { s->stats.rays_refraction += hc[4 * g + 2]; s->stats.rays_reflection += hc[4 * g + 1] - hc[4 * g + 2]; }
-    }
+  // the counters go to pinned host memory behind the kernels; finish_call() turns them into ray counts
+  rtx_scene::Call& c = cur_call(s);
+  const size_t words = (size_t)(max_gen + 2) * 4;
+  if (c.hc_words < words) {
+    if (c.hc) (void)hipHostFree(c.hc);
+    c.hc = nullptr; c.hc_words = 0;
+    HIP_TRY(hipHostMalloc((void**)&c.hc, (words + 64) * 4, hipHostMallocDefault));
+    c.hc_words = words + 64;
   }
+  HIP_TRY(hipMemcpyAsync(c.hc, s->w_counters.p, words * 4, hipMemcpyDeviceToHost, s->stream));
+  c.pipeline = true; c.shade = shade; c.shadows = opt->shadows != 0; c.max_gen = max_gen; c.NLS = NLS; c.G = G;
   return RTX_OK;
 }
 
 static int render_impl(rtx_scene* s, const DevCamera& C, uint32_t npix, uint32_t tiles, const rtx_options* opt,
-                       float* rgb, float* t, int32_t* face) {
-  stats_begin(s);
+                       float* rgb, float* t, int32_t* face, bool wait) {
+  if (int rc = stats_begin(s)) return rc;
   const size_t tab_cap = s->w_cam_tab.cap;
   if (int rc = s->w_cam_tab.ensure((size_t)(C.w + C.h) * 4)) return rc;
   if (s->w_cam_tab.cap != tab_cap) s->cam_tab_ok = false;      // a new allocation (maybe at the old address)
@@ -992,8 +1097,10 @@ static int render_impl(rtx_scene* s, const DevCamera& C, uint32_t npix, uint32_t
       live += (uint64_t)std::min(C.ts, C.w - gx * C.ts) * (uint64_t)std::min(C.ts, C.h - gy * C.ts);
     }
   }
-  s->stats.rays_primary = live;
-  tune_update(s);
+  cur_call(s).stats.rays_primary = live;
+  cur_call(s).tune = true;
+  if (wait) return stats_end(s);
+  stats_enqueue_end(s);
   return RTX_OK;
 }
 
@@ -1017,12 +1124,13 @@ extern "C" int rtx_trace_shade(rtx_scene* s, const rtx_options* opt, const float
   if (int rc = s->w_rays[0].ensure((size_t)max_nodes * 32)) return rc;
   HIP_TRY(hipMemcpyAsync(s->w_io[0].p, o, b3, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipMemcpyAsync(s->w_io[1].p, d, b3, hipMemcpyHostToDevice, s->stream));
-  stats_begin(s);
+  if (int rc = stats_begin(s)) return rc;
   hipLaunchKernelGGL(k_make_nodes, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->w_io[0].as<float>(), s->w_io[1].as<float>(), n,
                      inside ? 1 : 0, s->w_rays[0].as<float4>());
   Primary pr; pr.camera = false; std::memset(&pr.C, 0, sizeof pr.C); pr.n0 = n; pr.tiles = 0; pr.bounce0 = bounce;
   if (int rc = run_pipeline(s, pr, opt, s->w_io[2].as<float>(), nullptr, nullptr)) return rc;
-  s->stats.rays_primary = n;
+  cur_call(s).stats.rays_primary = n;
+  if (int rc = stats_end(s)) return rc;
   HIP_TRY(hipMemcpy(rgb, s->w_io[2].p, b3, hipMemcpyDeviceToHost));
   return RTX_OK;
 }

@@ -283,6 +283,58 @@ def test_tiled_compact_layout_equals_full_frame(api):
     s.close()
 
 
+@pytest.mark.gpu
+def test_enqueued_frames_equal_synchronous_ones(api):
+    """rtx_render_dev_enqueue / rtx_render_finish (two frames in flight, for sequences of frames):
+    different cameras alternate so that a stale table or buffer would show; every frame and its ray
+    counts must equal the synchronous call's, and misuse is reported, not executed."""
+    import torch
+    fx = load_scene_fixture("twoObjects")
+    s = make_scene(api, fx)
+    W = H = int(fx["res"])
+    opts = ns_options(api, bounces=2)
+    cams = [api.make_camera(fx["view_" + c], W, H) for c in CAMS]
+    want, want_stats = [], []
+    for cam in cams:
+        want.append(s.render(cam, opts, (0, 0, W, H)))
+        st = s.stats()
+        want_stats.append((st.rays_primary, st.rays_shadow, st.rays_reflection))
+    with pytest.raises(api.RtxError):
+        s.render_finish()                      # nothing enqueued
+    bufs = [(torch.zeros((H, W, 3), dtype=torch.float32, device="cuda"), torch.zeros((H, W), dtype=torch.float32, device="cuda"),
+             torch.zeros((H, W), dtype=torch.int32, device="cuda")) for _ in range(2)]
+    torch.cuda.synchronize()
+    order = [k % len(cams) for k in range(7)]
+    got = []
+
+    def collect(k):
+        st = s.render_finish()
+        rgb, t, face = bufs[k % 2]
+        got.append((order[k], rgb.cpu().numpy(), t.cpu().numpy(), face.cpu().numpy(), (st.rays_primary, st.rays_shadow, st.rays_reflection)))
+
+    for k, ci in enumerate(order):
+        rgb, t, face = bufs[k % 2]
+        s.render_dev_enqueue(cams[ci], opts, (0, 0, W, H), rgb.data_ptr(), t.data_ptr(), face.data_ptr())
+        if k >= 1:
+            collect(k - 1)                      # frame k-1 while frame k runs
+    collect(len(order) - 1)
+    assert len(got) == len(order)
+    for ci, rgb, t, face, st in got:
+        assert np.array_equal(face, want[ci][2])
+        assert_bits_equal(t, want[ci][1], "t")
+        assert_bits_equal(rgb, want[ci][0], "rgb")
+        assert st == want_stats[ci]
+    # a synchronous call finishes whatever is in flight
+    rgb, t, face = bufs[0]
+    s.render_dev_enqueue(cams[0], opts, (0, 0, W, H), rgb.data_ptr(), t.data_ptr(), face.data_ptr())
+    again = s.render(cams[1], opts, (0, 0, W, H))
+    assert_bits_equal(again[0], want[1][0], "rgb after a mixed sequence")
+    assert_bits_equal(rgb.cpu().numpy(), want[0][0], "enqueued frame finished by the synchronous call")
+    with pytest.raises(api.RtxError):
+        s.render_finish()
+    s.close()
+
+
 REF_OPTS = (2, 1, 1, 8, 1, 0)     # the reference itself: MAX_BOUNCES 2, reflect + refract, 8 GI probes, shadows
 
 
