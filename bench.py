@@ -139,10 +139,10 @@ def main():
     kmax = tiles.max_local_tiles(W, H, TILE, world)
     # one rank owns the whole frame: render it row-major in place, nothing to gather or reassemble
     npix_local = kmax * TILE * TILE if world > 1 else W * H
-    # Two sets of output buffers: the render of frame k+1 (librtx's own stream) overlaps the gather
+    # Three sets of output buffers: the render of frame k+1 (librtx's own stream) overlaps the gather
     # and reassembly of frame k (torch's streams); a set is reused only after the torch work that
     # read it has finished (event per set).
-    NSETS = 2
+    NSETS = 3
     sets = []
     for _ in range(NSETS):
         b = {"rgb": torch.zeros((npix_local, 3), dtype=torch.float32, device=dev),
@@ -155,6 +155,22 @@ def main():
         b["free"].record()
         sets.append(b)
     state = {"k": 0}
+
+    def exchange(b, out, face):
+        """The finished local pixels -> the frame on rank 0 (None elsewhere)."""
+        if world == 1:
+            return (out.view(H, W, 3), face.view(H, W, 1))
+        if rehearse:
+            g_rgb = tiles.gather_to_root(out.cpu(), world, rank, dist)
+            g_face = tiles.gather_to_root(face.cpu(), world, rank, dist)
+            if rank == 0:
+                g_rgb, g_face = g_rgb.to(dev), g_face.to(dev)
+        else:
+            g_rgb = tiles.gather_to_root(out, world, rank, dist, b.get("g_rgb"))
+            g_face = tiles.gather_to_root(face, world, rank, dist, b.get("g_face"))
+        if rank == 0:
+            return (tiles.assemble(g_rgb, W, H, TILE, 3), tiles.assemble(g_face, W, H, TILE, 1))
+        return None
 
     def frame():
         """One frame: render my tiles (all spp passes), gather to rank 0, assemble."""
@@ -184,40 +200,32 @@ def main():
             if acc is not None:
                 acc.add_(rgb)
         out = rgb if acc is None else acc.mul_(1.0 / len(cams))
-        if rehearse:
-            g_rgb = tiles.gather_to_root(out.cpu(), world, rank, dist)
-            g_face = tiles.gather_to_root(face.cpu(), world, rank, dist)
-            if rank == 0:
-                g_rgb, g_face = g_rgb.to(dev), g_face.to(dev)
-        elif world > 1:
-            g_rgb = tiles.gather_to_root(out, world, rank, dist, b.get("g_rgb"))
-            g_face = tiles.gather_to_root(face, world, rank, dist, b.get("g_face"))
-        if world > 1:
-            img = None
-            if rank == 0:
-                img = (tiles.assemble(g_rgb, W, H, TILE, 3), tiles.assemble(g_face, W, H, TILE, 1))
-        else:
-            img = (out.view(H, W, 3), face.view(H, W, 1))
+        img = exchange(b, out, face)
         b["free"].record()
         return rays, ms, img
 
-    # One rank, one sample per pixel: frames go through rtx_render_dev_enqueue / rtx_render_finish, frame
-    # k+1 queued before frame k is waited for, so the GPU does not idle while the host finishes a frame.
-    pipelined = world == 1 and len(cams) == 1
+    # One sample per pixel: frames go through the enqueue / finish entry points, frame k+1 queued before
+    # frame k is waited for (and, with several ranks, gathered), so the GPU does not idle while the host
+    # finishes a frame.  Several samples per pixel are accumulated by torch between passes: synchronous.
+    pipelined = len(cams) == 1
 
     def frame_enqueue():
         b = sets[state["k"] % NSETS]
         state["k"] += 1
         b["free"].synchronize()
-        scene.render_dev_enqueue(cams[0], opts, rect, b["rgb"].data_ptr(), None, b["face"].data_ptr())
+        if world > 1:
+            scene.render_tiles_dev_enqueue(cams[0], opts, rect, TILE, rank, world, b["rgb"].data_ptr(), None, b["face"].data_ptr())
+        else:
+            scene.render_dev_enqueue(cams[0], opts, rect, b["rgb"].data_ptr(), None, b["face"].data_ptr())
         return b
 
     def frame_finish(b):
         st = scene.render_finish()
         rays = [st.rays_primary, st.rays_shadow, st.rays_reflection]
         ms = [st.ms_trace_camera, st.ms_trace - st.ms_trace_camera, st.ms_total]
+        img = exchange(b, b["rgb"], b["face"])
         b["free"].record()
-        return rays, ms, (b["rgb"].view(H, W, 3), b["face"].view(H, W, 1))
+        return rays, ms, img
 
     def frames(n):
         """n frames; returns the per-frame (rays, ms, img) tuples."""
@@ -272,8 +280,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "triangles": int(info.ntris), "bvh_nodes": int(info.nnodes),
                        "image": [W, H], "lights": len(wl["lights"]), "spp": wl["spp"], "max_bounces": wl["opts"][0],
-                       "tile": TILE, "partition": ("image tiles round-robin over %d ranks, scene replicated, gather to rank 0" % world) if world > 1
-                       else "one rank renders the whole frame row-major" + (", two frames in flight (rtx_render_dev_enqueue)" if pipelined else ""),
+                       "tile": TILE, "partition": (("image tiles round-robin over %d ranks, scene replicated, gather to rank 0" % world) if world > 1
+                                     else "one rank renders the whole frame row-major") + ("; two frames in flight (rtx_render_*_enqueue / rtx_render_finish)" if pipelined else ""),
                        "rays_per_frame": {"primary": int(agg[0].item() / args.steps), "shadow": int(agg[1].item() / args.steps),
                                           "reflection": int(agg[2].item() / args.steps)},
                        "pixels_hitting_geometry": hits,

@@ -229,6 +229,10 @@ int rtx_tiles_count(rtx_rect rect, int32_t tile_size, int32_t part, int32_t npar
 int rtx_render_tiles_dev(rtx_scene*, const rtx_camera*, const rtx_options*, rtx_rect rect,
                          int32_t tile_size, int32_t part, int32_t nparts,
                          float* rgb, float* t, int32_t* face_id);
+/* ... and its enqueue form, finished by rtx_render_finish like rtx_render_dev_enqueue. */
+int rtx_render_tiles_dev_enqueue(rtx_scene*, const rtx_camera*, const rtx_options*, rtx_rect rect,
+                                 int32_t tile_size, int32_t part, int32_t nparts,
+                                 float* rgb, float* t, int32_t* face_id);
 
 int rtx_get_stats(const rtx_scene*, rtx_stats*);
 

@@ -49,7 +49,7 @@ SYMBOLS = ["rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_
            "rtx_scene_add_material", "rtx_scene_set_spheres", "rtx_scene_set_lights", "rtx_scene_build", "rtx_scene_commit",
            "rtx_scene_get_tris",
            "rtx_scene_get_info", "rtx_scene_get_bvh", "rtx_trace_closest", "rtx_trace_closest_dev",
-           "rtx_trace_visible", "rtx_render", "rtx_render_dev", "rtx_render_dev_enqueue", "rtx_render_finish", "rtx_tiles_count", "rtx_render_tiles_dev",
+           "rtx_trace_visible", "rtx_render", "rtx_render_dev", "rtx_render_dev_enqueue", "rtx_render_finish", "rtx_tiles_count", "rtx_render_tiles_dev", "rtx_render_tiles_dev_enqueue",
            "rtx_get_stats", "rtx_scene_build_reference_leafboxes", "rtx_scene_set_leafboxes",
            "rtx_scene_get_leafboxes", "rtx_intersect_box", "rtx_trace_shade", "rtx_camera_points", "rtx_scene_set_flags",
            "rtx_scene_get_packed_bvh", "rtx_debug_hit"]
@@ -63,12 +63,29 @@ class RtxError(RuntimeError):
     pass
 
 
+def _load_torch_first():
+    """The torch wheel brings its own copy of the HIP / HSA runtime libraries, librtx.so binds to the
+    ones under /opt/rocm.  A process can hold both when torch's are loaded first (bench.py, the tests);
+    the other way round torch finds no device afterwards ("No HIP GPUs are available", seen on the
+    MI355X box).  So where torch is installed it is imported before librtx.so is opened; without torch
+    nothing happens here -- the library itself does not need it."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or importlib.util.find_spec("torch") is None:
+        return
+    try:
+        import torch  # noqa: F401
+    except Exception:   # a broken torch install must not keep the library from loading
+        pass
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError("librtx.so is missing (%s): build it with __graft_entry__.build(); "
                               "there is no CPU fallback" % LIB_PATH)
+        _load_torch_first()
         L = C.CDLL(LIB_PATH)
         L.rtx_last_error.restype = C.c_char_p
         L.rtx_scene_create.argtypes = [_f, C.c_uint32, _u, _i, C.c_uint32, C.POINTER(Material), C.c_uint32,
@@ -103,6 +120,8 @@ def lib():
         L.rtx_debug_hit.argtypes = [C.c_void_p, _f, _f, C.c_uint32, _f, C.POINTER(C.c_int32), _f, _f, C.POINTER(C.c_uint8)]
         L.rtx_tiles_count.argtypes = [Rect, C.c_int32, C.c_int32, C.c_int32]
         L.rtx_render_tiles_dev.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Options), Rect, C.c_int32,
+                                           C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rtx_render_tiles_dev_enqueue.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Options), Rect, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -326,6 +345,11 @@ class Scene:
         x0, y0, x1, y1 = rect
         _check(lib().rtx_render_tiles_dev(self.h, C.byref(cam), C.byref(opts), Rect(x0, y0, x1, y1), tile_size, part,
                                           nparts, rgb_ptr, t_ptr, face_ptr))
+
+    def render_tiles_dev_enqueue(self, cam, opts, rect, tile_size, part, nparts, rgb_ptr, t_ptr, face_ptr):
+        x0, y0, x1, y1 = rect
+        _check(lib().rtx_render_tiles_dev_enqueue(self.h, C.byref(cam), C.byref(opts), Rect(x0, y0, x1, y1), tile_size, part,
+                                                  nparts, rgb_ptr, t_ptr, face_ptr))
 
     def stats(self):
         s = Stats()

@@ -952,21 +952,34 @@ extern "C" int rtx_tiles_count(rtx_rect rect, int32_t tile_size, int32_t part, i
   return (int)((total - part + nparts - 1) / nparts);
 }
 
-extern "C" int rtx_render_tiles_dev(rtx_scene* s, const rtx_camera* cam, const rtx_options* opt, rtx_rect rect,
-                                    int32_t tile_size, int32_t part, int32_t nparts, float* rgb, float* t, int32_t* face) {
+static int render_tiles_impl(rtx_scene* s, const rtx_camera* cam, const rtx_options* opt, rtx_rect rect, int32_t tile_size,
+                             int32_t part, int32_t nparts, float* rgb, float* t, int32_t* face, bool wait) {
   if (int rc = check_ready(s)) return rc;
   if (int rc = check_render_args(s, cam, opt, rgb)) return rc;
   const int nt = rtx_tiles_count(rect, tile_size, part, nparts);
   if (nt < 0) return nt;
   DevCamera C{};
   if (int rc = make_camera(cam, rect, &C)) return rc;
-  if (nt == 0) return RTX_OK;
+  if (nt == 0) {                       // a part without tiles: an empty call, so that enqueue / finish still pair up
+    if (wait) return RTX_OK;
+    if (int rc = stats_begin(s)) return rc;
+    stats_enqueue_end(s);
+    return RTX_OK;
+  }
   if ((int64_t)nt * tile_size * tile_size >= (1ll << 31)) return fail(RTX_ELIMIT, "too many pixels in this part");
   C.ts = tile_size; C.part = part; C.nparts = nparts; C.tiles_x = (C.w + tile_size - 1) / tile_size;
   C.ntiles_local = (uint32_t)nt;
   const uint32_t npix = (uint32_t)nt * (uint32_t)(tile_size * tile_size);
   const uint32_t nblocks = (uint32_t)nt * (uint32_t)((tile_size / 16) * (tile_size / 16));
-  return render_impl(s, C, npix, nblocks, opt, rgb, t, face);
+  return render_impl(s, C, npix, nblocks, opt, rgb, t, face, wait);
+}
+extern "C" int rtx_render_tiles_dev(rtx_scene* s, const rtx_camera* cam, const rtx_options* opt, rtx_rect rect,
+                                    int32_t tile_size, int32_t part, int32_t nparts, float* rgb, float* t, int32_t* face) {
+  return render_tiles_impl(s, cam, opt, rect, tile_size, part, nparts, rgb, t, face, true);
+}
+extern "C" int rtx_render_tiles_dev_enqueue(rtx_scene* s, const rtx_camera* cam, const rtx_options* opt, rtx_rect rect,
+                                            int32_t tile_size, int32_t part, int32_t nparts, float* rgb, float* t, int32_t* face) {
+  return render_tiles_impl(s, cam, opt, rect, tile_size, part, nparts, rgb, t, face, false);
 }
 
 // The generation loop of the ray queue.  Primary nodes are either the pixels of a camera
