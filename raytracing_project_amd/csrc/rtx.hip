@@ -345,6 +345,7 @@ extern "C" int rtx_scene_build(rtx_scene* s) {
   float scene_abs = 0.0f;
   for (size_t i = 0; i < s->verts.size(); ++i) scene_abs = std::max(scene_abs, std::fabs(s->verts[i]));
   const float pad_abs = std::max(2e-5f * scene_abs, 1e-30f);
+  const double kWildBelow = [] { const char* e = std::getenv("RTX_WILD_BELOW"); const double v = e ? std::atof(e) : 0.0; return v > 0 ? v : 2.5e-6; }();   // (tuning / test hook)
   auto vert = [&](uint32_t i) { return v3(s->verts[3 * i], s->verts[3 * i + 1], s->verts[3 * i + 2]); };
   for (uint32_t f = 0; f < ntris; ++f) {
     const V3 a = vert(s->idx[3 * f]), b = vert(s->idx[3 * f + 1]), c = vert(s->idx[3 * f + 2]);
@@ -360,15 +361,18 @@ extern "C" int rtx_scene_build(rtx_scene* s) {
     int32_t m = s->tri_mat[f];
     float mw; std::memcpy(&mw, &m, 4);
     face_nm[f] = make_float4(nq.x, nq.y, nq.z, mw);
-    // Conservative culling box.  The reference's isInTriangle (src/Intersect.cpp:24-46) works
-    // on fp32 barycentrics; with q = sin^2(angle at v0) its denominator carries a relative
-    // error of ~15 eps / q and its numerators ~16 eps |w| |u| |v|^2, so the set of points it
-    // accepts reaches outside the exact triangle by about
-    //     40 eps / sqrt(q) * (1 + (|u| + |v|) / |v2 - v1|) * (longest edge).
-    // Boxes are padded by that plus margins for the plane-distance and slab rounding.  Below
-    // q = 1e-5 the denominator's sign is no longer trustworthy and the accepted set is
-    // unbounded: such triangles stay out of the hierarchy and are tested by every ray
-    // ("wild" list), which is what the reference's brute-force scan does for all of them.
+    // Conservative culling box.  The reference's isInTriangle (src/Intersect.cpp:24-46) works on fp32
+    // barycentrics s = s1 / D, t = t1 / D with D = uv^2 - uu vv.  With q = sin^2(angle at v0):
+    //  * D and the numerators lose ~15 eps / q of their value to cancellation, so the accepted set is the
+    //    exact triangle scaled about v0 by up to 1 + 15 eps / q: points up to that fraction of an edge
+    //    beyond the far edge, along the triangle, pass (measured 7.5e-7 / q on thin triangles, numpy
+    //    replay and the oracle; tests/test_cabi_host.py aims rays there);
+    //  * across the edges it reaches outside by about 40 eps / sqrt(q) * (1 + (|u| + |v|) / |v2 - v1|)
+    //    * (longest edge).
+    // Boxes are padded by both (the first with 1.2e-6 / q = 20 eps / q) plus margins for the plane
+    // distance and slab rounding.  Below q = 2.5e-6 (D off by a third and more, then its sign) the
+    // accepted set is no longer bounded: such triangles stay out of the hierarchy and are tested by
+    // every ray ("wild" list), which is what the reference's brute-force scan does for all of them.
     const double du[3] = {(double)b.x - a.x, (double)b.y - a.y, (double)b.z - a.z};
     const double dv[3] = {(double)c.x - a.x, (double)c.y - a.y, (double)c.z - a.z};
     const double de[3] = {dv[0] - du[0], dv[1] - du[1], dv[2] - du[2]};
@@ -377,11 +381,11 @@ extern "C" int rtx_scene_build(rtx_scene* s) {
     const double dee = de[0] * de[0] + de[1] * de[1] + de[2] * de[2];
     const double q = (duu * dvv > 0) ? (duu * dvv - duv * duv) / (duu * dvv) : 0.0;
     const bool finite_rec = std::isfinite(D) && std::isfinite(uu) && std::isfinite(vv) && std::isfinite(nq.x + nq.y + nq.z);
-    if (!(q >= 1e-5) || !(dee > 0) || !finite_rec) { wild.push_back(f); continue; }
+    if (!(q >= kWildBelow) || !(dee > 0) || !finite_rec) { wild.push_back(f); continue; }
     const double lu = std::sqrt(duu), lv = std::sqrt(dvv), le = std::sqrt(dee);
     const double longest = std::max(lu, std::max(lv, le));
     const double fuzz = 3e-6 / std::sqrt(q) * (1.0 + (lu + lv) / le);
-    const float pad = pad_abs + (float)(longest * (2e-3 + fuzz));
+    const float pad = pad_abs + (float)(longest * (2e-3 + fuzz) + std::max(lu, lv) * (1.2e-6 / q));
     const float pa[3] = {a.x, a.y, a.z}, pb[3] = {b.x, b.y, b.z}, pc[3] = {c.x, c.y, c.z};
     float bl[3], bh[3];
     for (int k = 0; k < 3; ++k) {

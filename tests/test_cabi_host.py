@@ -140,6 +140,89 @@ def test_host_bvh_equals_bruteforce_on_soup_and_random_rays(api, oa):
     assert_bits_equal(t, brute["t"], "t")
 
 
+def _slivers(rng, qs, per_q=40):
+    """Thin triangles: sin^2 of the angle at v0 = q, second edge 0.2-0.35 or 2.2-3 x the first (the culling boxes
+    have least slack there), both nearly collinear."""
+    tris = []
+    for q in qs:
+        c = rng.uniform(-1, 1, (per_q, 3))
+        u = rng.normal(size=(per_q, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+        w = rng.normal(size=(per_q, 3)); w -= (w * u).sum(1, keepdims=True) * u; w /= np.linalg.norm(w, axis=1, keepdims=True)
+        L = rng.uniform(0.1, 0.6, (per_q, 1))
+        k = np.where(rng.random((per_q, 1)) < 0.5, rng.uniform(0.2, 0.35, (per_q, 1)), rng.uniform(2.2, 3.0, (per_q, 1)))
+        tris.append(np.stack([c, c + u * L, c + (u * np.sqrt(1 - q) + w * np.sqrt(q)) * L * k], 1))
+    return np.concatenate(tris).astype(np.float32)
+
+
+def sliver_overshoot_rays(rng, T, n):
+    """Rays through points just past the far edge of thin triangles, along their long axis: the reference's
+    fp32 barycentric test (src/Intersect.cpp:24-46) loses ~15 eps / sin^2(angle) there and accepts points
+    up to that fraction of an edge beyond the triangle -- the culling boxes have to cover them."""
+    k = rng.integers(0, len(T), n)
+    a, b, c = T[k, 0].astype(np.float64), T[k, 1].astype(np.float64), T[k, 2].astype(np.float64)
+    du, dv = b - a, c - a
+    q = 1.0 - ((du * dv).sum(1) ** 2) / ((du * du).sum(1) * (dv * dv).sum(1))
+    # beyond the far edge by 2e-7/q .. 9e-7/q of an edge (the zone's outer half), near the end of the longer edge
+    x = rng.uniform(2e-7, 9e-7, n) / np.maximum(q, 1e-12)
+    x = np.minimum(x, 0.5)
+    sp = rng.uniform(0.0, 0.25, n)
+    longer_u = (du * du).sum(1) > (dv * dv).sum(1)
+    sp = np.where(longer_u, 1.0 - sp, sp)
+    P = a + ((1 + x) * sp)[:, None] * du + ((1 + x) * (1 - sp))[:, None] * dv
+    nrm = np.cross(du, dv); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    side = rng.normal(size=(n, 3)) * 0.3
+    org = (P + nrm * rng.uniform(0.3, 1.5, (n, 1)) * rng.choice([-1.0, 1.0], (n, 1)) + side).astype(np.float32)
+    return org, (P - org).astype(np.float32)
+
+
+def sliver_clusters(rng, qs, per_q=12):
+    """Thin triangles far apart from each other (grid spacing 3, size <= 0.6), each with three tiny
+    companions at its corners: the hierarchy's leaves (<= 4 triangles) then are these clusters and a
+    leaf's box is the thin triangle's own padded box, while the root box (the reference's gate) is large."""
+    S = _slivers(rng, qs, per_q)
+    n = len(S)
+    side = int(np.ceil(n ** (1.0 / 3.0)))
+    g = np.stack(np.unravel_index(np.arange(n), (side, side, side)), 1).astype(np.float64) * 3.0
+    S = (S.astype(np.float64) - S[:, :1].astype(np.float64) + g[:, None, :]).astype(np.float32)      # v0 on the grid point
+    tiny = []
+    for c in range(3):
+        e = rng.normal(size=(n, 3, 3)) * 2e-4
+        e[:, 0] = 0.0
+        inward = (S.mean(1) - S[:, c]) * 1e-3                 # just inside the triangle's own bounding box
+        tiny.append((S[:, c:c + 1].astype(np.float64) + inward[:, None, :] + e * 0.5).astype(np.float32))
+    T = np.concatenate([S] + tiny)
+    return T, n
+
+
+def test_host_bvh_covers_what_the_fp32_test_accepts_beyond_thin_triangles(api, oa):
+    """Rays through the overshoot zone of thin triangles whose leaves are tight: every hit the brute-force
+    scan reports must survive the hierarchy (fp32 boxes, CPU mirror of the traversal)."""
+    rng = np.random.default_rng(77)
+    T, nthin = sliver_clusters(rng, (3e-6, 1.05e-5, 1.2e-5, 1.5e-5, 2e-5, 5e-5, 1e-4, 1e-3), per_q=6)
+    verts, idx = T.reshape(-1, 3), np.arange(3 * len(T), dtype=np.uint32).reshape(len(T), 3)
+    s = api.Scene(verts, idx, None, [api.make_material()])
+    s.build()
+    info = s.info()
+    nodes, order = s.bvh()
+    tris = s.tris()
+    os_ = oa.Scene(verts, idx, None, [oa.make_mtl()])
+    lo, hi = os_.root_box()
+    o, d = sliver_overshoot_rays(rng, T[:nthin], 400000)
+    brute = os_.closest(o, d, threads=8)
+    d1 = np.zeros_like(d)
+    oo = np.zeros(3, np.float32)
+    for i in range(len(o)):
+        oa.lib().ora_ray(oa.fp(o[i]), oa.fp(d[i]), oa.fp(oo), oa.fp(d1[i]))
+    t, face, nv, tt = oa.bvh_trace(nodes, tris, order, lo, hi, o, d1, threads=8, nwild=info.nwild)
+    hits = int((brute["face"] >= 0).sum())
+    assert hits > 1000
+    bad = np.nonzero(face != brute["face"])[0]
+    assert len(bad) == 0, "%d of %d hits of the brute-force scan are lost behind the culling boxes (first: ray %d, face %d)" % (
+        len(bad), hits, bad[0], brute["face"][bad[0]])
+    assert_bits_equal(t, brute["t"], "t")
+    s.close()
+
+
 def test_empty_and_degenerate_scenes_build(api):
     s = api.Scene(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32), None, [])
     s.build()

@@ -677,6 +677,29 @@ def test_nasty_geometry_random_rays_vs_bruteforce(api, oa):
 
 
 @pytest.mark.gpu
+def test_thin_triangles_overshoot_zone_vs_bruteforce(api, oa):
+    """Rays through the zone just past the far edge of thin triangles, where the reference's fp32
+    barycentric test still accepts (up to ~15 eps / sin^2 of an edge length): the device's padded and
+    quantised boxes must let every such hit through.  Same construction as the host-side test."""
+    from test_cabi_host import sliver_clusters, sliver_overshoot_rays
+    rng = np.random.default_rng(78)
+    T, nthin = sliver_clusters(rng, (3e-6, 1.05e-5, 1.2e-5, 1.5e-5, 2e-5, 5e-5, 1e-4, 1e-3), per_q=6)
+    verts, idx = T.reshape(-1, 3), np.arange(3 * len(T), dtype=np.uint32).reshape(len(T), 3)
+    s = api.Scene(verts, idx, None, [api.make_material()])
+    s.set_lights([[-2.0, 2.0, 2.0]])
+    s.commit(0)
+    o = oa.Scene(verts, idx, None, [oa.make_mtl()])
+    org, d = sliver_overshoot_rays(rng, T[:nthin], 400000)
+    t, face = s.trace_closest(org, d)
+    h = o.closest(org, d, threads=16)
+    assert (h["face"] >= 0).sum() > 1000
+    bad = np.nonzero(face != h["face"])[0]
+    assert len(bad) == 0, "%d rays differ, first %d: gpu %d vs %d" % (len(bad), bad[0], face[bad[0]], h["face"][bad[0]])
+    assert_bits_equal(t, h["t"], "t")
+    s.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["planeobj", "cube", "twoObjects", "toy"])
 def test_debug_hit_vs_oracle(api, oa, name):
     """rtx_debug_hit == the hit search of Flyscene::ReflectDebugRay (leaf list, isInBox / t > 0
