@@ -13,7 +13,7 @@
  * independent (one HIP stream each).  The reference mutates its scene only between
  * renders (src/main.cpp:63-77); so does this API (mutators need a new rtx_scene_commit).
  *
- * Limits (RTX_ELIMIT beyond them): fewer than 2^28 triangles; fewer than 2^31 pixels per call
+ * Limits (RTX_ELIMIT beyond them): fewer than 2^28 triangles and 2^26 BVH node groups (~1.4e8 triangles); fewer than 2^31 pixels per call
  * and fewer than 2^31 rays per query call and per ray generation of a render (pixels x light
  * samples, or x 2^bounces with reflection and refraction both on); max_bounces <= 16 (8 for
  * reflection + refraction trees); gi_rays <= 64.

@@ -428,6 +428,8 @@ extern "C" int rtx_scene_build(rtx_scene* s) {
   in.max_depth = s->bvh.quad_depth; in.nwild = s->nwild; in.nslots = s->bvh.quad_slots;
   in.build_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
   if (3 * s->bvh.quad_depth > (uint32_t)kStackDepth) return fail(RTX_ELIMIT, "BVH depth %u exceeds the traversal stack", s->bvh.quad_depth);
+  // a node entry is a group index whose byte offset (index * 64) the kernels keep in 32 bits
+  if (s->bvh.quads.size() / 4 >= (1u << 26)) return fail(RTX_ELIMIT, "BVH has %zu node groups, the device encoding holds fewer than 2^26", s->bvh.quads.size() / 4);
   s->built = true;
   return RTX_OK;
 }
