@@ -156,7 +156,8 @@ int rtx_scene_get_bvh(const rtx_scene*, uint32_t* nodes8, uint32_t* tri_face);
  * {origin.xyz, step_x (floats), entry[4], lox, loy, loz, hix, hiy, hiz, step_y, step_z (floats)}; plane =
  * origin + byte * step per axis (byte k of a plane word = child k; steps are powers of two), rounded
  * outwards; entry = 0x80000000 | count << 28 | first triangle (leaf), child group (internal),
- * 0xFFFFFFFF (unused).  Inspection only (tests); no counterpart in the reference. */
+ * 0x80000000 (unused: a leaf of no triangles, harmless to visit).  Inspection only (tests); no counterpart
+ * in the reference. */
 int rtx_scene_get_packed_bvh(const rtx_scene*, uint32_t* groups16);
 /* Host copy of the leaf-ordered 64-byte triangle records: ntris x 16 floats
  * {v0.xyz, D}{u.xyz, u.u}{v.xyz, u.v}{n.xyz, v.v} (src/Intersect.cpp:10,26-32 hoisted per triangle). */

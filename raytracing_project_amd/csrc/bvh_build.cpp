@@ -332,7 +332,7 @@ void pack_groups(const std::vector<BvhNode>& quads, std::vector<PackedGroup>* ou
     P.lox = planes[0]; P.loy = planes[1]; P.loz = planes[2]; P.hix = planes[3]; P.hiy = planes[4]; P.hiz = planes[5];
     for (int k = 0; k < 4; ++k) {
       const BvhNode& nd = q[k];
-      if (nd.leftFirst == kEmptySlot && nd.count == 0) P.entry[k] = kEmptySlot;
+      if (nd.leftFirst == kEmptySlot && nd.count == 0) P.entry[k] = kEmptyPacked;
       else if (nd.count) P.entry[k] = 0x80000000u | (nd.count << 28) | nd.leftFirst;
       else P.entry[k] = nd.leftFirst;
     }

@@ -19,6 +19,10 @@ static_assert(sizeof(BvhNode) == 32, "node must be 32 bytes");
 
 // Marks an unused slot of a 4-slot group (see collapse_to_quads).
 constexpr uint32_t kEmptySlot = 0xFFFFFFFFu;
+// ... and in the packed encoding: a leaf without triangles.  The kernels never mean to visit it (its planes are
+// inverted, so no finite ray enters it), but a ray with NaN or overflowing coordinates fails every comparison
+// and may: the entry must then be harmless to follow (the first fuzzing run faulted the GPU on 0xFFFFFFFF).
+constexpr uint32_t kEmptyPacked = 0x80000000u;
 
 struct BvhBuildResult {
   std::vector<BvhNode> quads;      // traversal layout: groups of 4 sibling slots, group 0 = children of the root
@@ -51,7 +55,7 @@ void collapse_to_quads(BvhBuildResult* out);
 //   origin[3]   group lower corner (fp32)
 //   step_x/y/z  power-of-two step of each axis (fp32, 2^e with e chosen so that 255 steps span the group)
 //   entry[4]    traversal entries: leaf = 0x80000000 | count << 28 | first triangle,
-//               internal = child group index, unused = 0xFFFFFFFF
+//               internal = child group index, unused = 0x80000000 (kEmptyPacked)
 //   lox..hiz    byte k = child k's plane in steps from origin (lower planes rounded down,
 //               upper planes rounded up); an unused slot has lower planes 255 and upper planes 0
 struct PackedGroup {

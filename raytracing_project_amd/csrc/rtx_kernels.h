@@ -39,7 +39,6 @@ constexpr int kLdsStack = 13;        // the first entries live in LDS (13 KB + 9
 constexpr int kLdsStackGroups = 16;  // same for the group-by-group scheduler, which parks nothing
                                      // deeper ones (rare) spill to a per-thread global column
 constexpr uint32_t kLeafBit = 0x80000000u;
-constexpr uint32_t kEmptyRef = 0xFFFFFFFFu;   // unused slot of a 4-node group
 constexpr float kPrecision = 0.001f; // Intersect::Face::precision (src/Intersect.h:14)
 constexpr float kPruneSlack = 1.0001f;
 
@@ -134,6 +133,14 @@ struct Hit { float t; int id; };   // id >= 0 mesh face, -1 miss, <= -2 sphere (
 __device__ __forceinline__ float cull_inv(float d) {
   const float iv = 1.0f / d;
   return (fabsf(iv) <= 1e18f) ? iv : copysignf(1e18f, d);
+}
+
+// A ray with a NaN or an infinity among its six numbers hits nothing in the reference (every comparison of
+// Triangle::intersects fails, or t is infinite and loses against any hit or the miss alike), so the
+// hierarchy need not be walked for it -- and should not be: its slab tests all "pass" and it would visit
+// every node.  x - x is 0 for a finite x and NaN otherwise.
+__device__ __forceinline__ bool ray_is_finite(V3 o, V3 d) {
+  return ((o.x - o.x) + (o.y - o.y) + (o.z - o.z)) + ((d.x - d.x) + (d.y - d.y) + (d.z - d.z)) == 0.0f;
 }
 
 // Intersect::Triangle::intersects + isInTriangle (src/Intersect.cpp:6-46) on leaf-ordered
@@ -321,7 +328,9 @@ __device__ __forceinline__ bool node_step(const DevScene& S, const StackT& stk, 
   // Which plane of each axis the ray enters through depends on the sign of the direction only:
   // pick the words once per step instead of a min and a max per child and axis.  An unused slot
   // is encoded inverted (lower planes 255, upper planes 0), so that its entry lies beyond its
-  // exit whatever the signs -- no separate "empty" test.
+  // exit whatever the signs -- no separate "empty" test.  (That holds for finite arithmetic; a ray with NaN or
+  // overflowing coordinates fails every comparison and can "hit" such a slot, so its entry word is a leaf of
+  // no triangles, harmless to follow.)
   const bool nx = ivx < 0.0f, ny = ivy < 0.0f, nz = ivz < 0.0f;
   const uint32_t wnx = nx ? h2.w : h2.x, wfx = nx ? h2.x : h2.w;
   const uint32_t wny = ny ? h3.x : h2.y, wfy = ny ? h2.y : h3.x;
@@ -477,7 +486,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& S, const Source& src,
             sd = normalized(sd1);
             if ((S.flags & 1u) || ref_box_t(so, sd, S.root_lo, S.root_hi) != INFINITY) {
               for (uint32_t k = S.ntris - S.nwild; k < S.ntris; ++k) test_triangle(S, k, so, sd, &sb);
-              park = S.nwild != S.ntris;
+              park = S.nwild != S.ntris && ray_is_finite(so, sd);
             }
           }
           if (src.first_hit_decides() && sb.id != -1 && sb.t < 0.998f * src.tmax_of(sslot)) park = false;
@@ -582,7 +591,7 @@ __device__ __forceinline__ void trace_wave_groups(const DevScene& S, const Sourc
         d = normalized(d1);
         if ((S.flags & 1u) || ref_box_t(o, d, S.root_lo, S.root_hi) != INFINITY) {
           for (uint32_t k = S.ntris - S.nwild; k < S.ntris; ++k) test_triangle(S, k, o, d, &best);
-          walk = S.nwild != S.ntris;
+          walk = S.nwild != S.ntris && ray_is_finite(o, d);
         }
       }
       if (src.first_hit_decides() && best.id != -1 && best.t < 0.998f * src.tmax_of(slot)) walk = false;

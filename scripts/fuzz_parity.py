@@ -1,0 +1,116 @@
+"""Differential fuzzing of the closest-hit path on the GPU against the oracle's brute-force scan.
+
+    python3 scripts/fuzz_parity.py [seconds] [first seed]
+
+Random meshes (soups of several densities, thin triangles on both sides of the wild threshold, flat and
+duplicated faces, clusters at very different scales) x random rays (through points of triangles, their
+vertices and edges, the zone just past thin triangles, axis-parallel, from far away, from inside), hit ids
+and t compared bit for bit.  Prints one line per scene; exits 1 on the first difference (and says which
+seed, so that it can be replayed).  Needs a GPU; the tests hold the distilled cases.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import oracle_api as oa  # noqa: E402
+from raytracing_project_amd import api, scenes  # noqa: E402
+from test_cabi_host import _slivers, sliver_overshoot_rays  # noqa: E402
+
+
+def mesh(rng):
+    parts = []
+    kind = rng.integers(0, 4)
+    if kind == 0:      # a soup
+        v, i = scenes.soup(int(rng.integers(500, 20000)), seed=int(rng.integers(1, 1 << 30)), h=float(10 ** rng.uniform(-2.2, -0.7)))
+        parts.append(v[i.astype(np.int64)].reshape(-1, 3, 3))
+    elif kind == 1:    # clusters at different scales
+        for _ in range(int(rng.integers(2, 6))):
+            sc = 10 ** rng.uniform(-2.5, 1.0)
+            c = rng.uniform(-1, 1, (1, 1, 3)) * 10 ** rng.uniform(-1, 1)
+            n = int(rng.integers(50, 1500))
+            parts.append(c + rng.uniform(-1, 1, (n, 1, 3)) * sc + rng.uniform(-0.15, 0.15, (n, 3, 3)) * sc)
+    elif kind == 2:    # a grid surface with jitter (closed-surface-like coherence) plus walls
+        n = int(rng.integers(20, 90))
+        xs, ys = np.meshgrid(np.linspace(-1, 1, n), np.linspace(-1, 1, n))
+        z = 0.2 * np.sin(3 * xs) * np.cos(2 * ys) + rng.normal(size=xs.shape) * 0.002
+        P = np.stack([xs, ys, z], -1)
+        a, b, c, d = P[:-1, :-1], P[1:, :-1], P[:-1, 1:], P[1:, 1:]
+        parts.append(np.concatenate([np.stack([a, b, c], 2).reshape(-1, 3, 3), np.stack([b, d, c], 2).reshape(-1, 3, 3)]))
+    else:
+        parts.append(rng.uniform(-1, 1, (int(rng.integers(200, 3000)), 1, 3)) + rng.uniform(-0.3, 0.3, (1, 3, 3)) * rng.uniform(0.01, 1, (1, 1, 1)))
+    if rng.random() < 0.7:
+        qs = tuple(10 ** rng.uniform(-8, -2, int(rng.integers(2, 8))))
+        parts.append(_slivers(rng, qs, per_q=int(rng.integers(4, 30))).astype(np.float64) * 10 ** rng.uniform(-1, 0.5))
+    if rng.random() < 0.4:
+        ax = int(rng.integers(0, 3))
+        t = rng.uniform(-1, 1, (int(rng.integers(10, 200)), 3, 3))
+        t[:, :, ax] = rng.uniform(-1, 1, (len(t), 1))
+        parts.append(t)
+    T = np.concatenate(parts).astype(np.float32)
+    if rng.random() < 0.5:
+        T = np.concatenate([T, T[: max(1, len(T) // 20)][::-1]])          # duplicates: ties
+    if rng.random() < 0.3:
+        Z = T[::53].copy(); Z[:, 2] = Z[:, 1]
+        T = np.concatenate([T, Z])                                          # zero-area faces
+    return T
+
+
+def rays(rng, T, n):
+    ext = float(np.abs(T).max())
+    org = rng.uniform(-1.5, 1.5, (n, 3)) * ext
+    d = rng.normal(size=(n, 3))
+    k = rng.integers(0, len(T), n)
+    Td = T.astype(np.float64)
+    bary = rng.dirichlet([1, 1, 1], n)
+    target = (Td[k] * bary[:, :, None]).sum(1)
+    d[0::2] = (target - org)[0::2]
+    d[1::8] = (Td[k, rng.integers(0, 3, n)] - org)[1::8]
+    e0 = rng.integers(0, 3, n); tt = rng.uniform(0, 1, (n, 1))
+    edge_pt = Td[k, e0] * tt + Td[k, (e0 + 1) % 3] * (1 - tt)
+    d[3::8] = (edge_pt - org)[3::8]
+    d[5::16, 0] = 0.0; d[7::16, 1] = 0.0; d[9::16, 2] = 0.0
+    far = slice(11, n, 32)
+    org[far] *= 25.0; d[far] = (target - org)[far]
+    inside = slice(13, n, 32)                       # origins on a surface point, going anywhere
+    org[inside] = target[inside]
+    org = org.astype(np.float32); d = d.astype(np.float32)
+    o2, d2 = sliver_overshoot_rays(rng, T, n // 4)
+    return np.concatenate([org, o2]), np.concatenate([d, d2])
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t0 = time.time()
+    scenes_done = rays_done = 0
+    while time.time() - t0 < budget:
+        rng = np.random.default_rng(seed)
+        T = mesh(rng)
+        verts, idx = T.reshape(-1, 3), np.arange(3 * len(T), dtype=np.uint32).reshape(len(T), 3)
+        n = int(min(400000, max(20000, 4e9 / len(T) / 8)))
+        org, d = rays(rng, T, n)
+        s = api.Scene(verts, idx, None, [api.make_material()])
+        s.set_lights([[0.0, 3.0, 0.0]])
+        s.commit(0)
+        t, face = s.trace_closest(org, d)
+        nwild = s.info().nwild
+        s.close()
+        h = oa.Scene(verts, idx, None, [oa.make_mtl()]).closest(org, d, threads=16)
+        bad = np.nonzero((face != h["face"]) | (t.view(np.uint32) != h["t"].view(np.uint32)))[0]
+        print("seed %d: %6d triangles (%3d wild), %6d rays, %6d hits, %d differ" % (seed, len(T), nwild, len(org), int((h["face"] >= 0).sum()), len(bad)),
+              flush=True)
+        if len(bad):
+            i = bad[0]
+            print("  first: ray %d gpu (%d, %r) oracle (%d, %r) o=%r d=%r" % (i, face[i], t[i], h["face"][i], h["t"][i], org[i], d[i]))
+            sys.exit(1)
+        scenes_done += 1; rays_done += len(org); seed += 1
+    print("fuzz ok: %d scenes, %d rays in %.0f s" % (scenes_done, rays_done, time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()

@@ -161,7 +161,7 @@ def sliver_overshoot_rays(rng, T, n):
     k = rng.integers(0, len(T), n)
     a, b, c = T[k, 0].astype(np.float64), T[k, 1].astype(np.float64), T[k, 2].astype(np.float64)
     du, dv = b - a, c - a
-    q = 1.0 - ((du * dv).sum(1) ** 2) / ((du * du).sum(1) * (dv * dv).sum(1))
+    q = 1.0 - ((du * dv).sum(1) ** 2) / np.maximum((du * du).sum(1) * (dv * dv).sum(1), 1e-300)
     # beyond the far edge by 2e-7/q .. 9e-7/q of an edge (the zone's outer half), near the end of the longer edge
     x = rng.uniform(2e-7, 9e-7, n) / np.maximum(q, 1e-12)
     x = np.minimum(x, 0.5)
@@ -169,7 +169,8 @@ def sliver_overshoot_rays(rng, T, n):
     longer_u = (du * du).sum(1) > (dv * dv).sum(1)
     sp = np.where(longer_u, 1.0 - sp, sp)
     P = a + ((1 + x) * sp)[:, None] * du + ((1 + x) * (1 - sp))[:, None] * dv
-    nrm = np.cross(du, dv); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    nrm = np.cross(du, dv)
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-300)     # (zero-area faces: no direction, the ray just starts next to P)
     side = rng.normal(size=(n, 3)) * 0.3
     org = (P + nrm * rng.uniform(0.3, 1.5, (n, 1)) * rng.choice([-1.0, 1.0], (n, 1)) + side).astype(np.float32)
     return org, (P - org).astype(np.float32)
@@ -290,5 +291,5 @@ def test_packed_groups_contain_the_fp32_boxes(api, name):
         assert (dlo[live] <= lo[live, k]).all() and (dhi[live] >= hi[live, k]).all()
         assert (lo[live, k] - dlo[live] <= step[live] * 1.001).all() and (dhi[live] - hi[live, k] <= step[live] * 1.001).all()
         want = np.where(cnt[:, k] > 0, 0x80000000 | (cnt[:, k] << 28) | ref[:, k], ref[:, k]).astype(np.uint32)
-        assert np.array_equal(g[live, 4 + k], want[live]) and (g[empty[:, k], 4 + k] == 0xFFFFFFFF).all()
+        assert np.array_equal(g[live, 4 + k], want[live]) and (g[empty[:, k], 4 + k] == 0x80000000).all()
     s.close()
