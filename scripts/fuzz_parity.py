@@ -5,7 +5,8 @@
 Random meshes (soups of several densities, thin triangles on both sides of the wild threshold, flat and
 duplicated faces, clusters at very different scales) x random rays (through points of triangles, their
 vertices and edges, the zone just past thin triangles, axis-parallel, from far away, from inside), hit ids
-and t compared bit for bit.  Prints one line per scene; exits 1 on the first difference (and says which
+and t compared bit for bit; plus a 48x48 frame through the whole pipeline (shadows, up to 2 reflections;
+one or several materials) against the oracle's render, ids and t bit for bit, RGB within 1e-4.  Prints one line per scene; exits 1 on the first difference (and says which
 seed, so that it can be replayed).  Needs a GPU; the tests hold the distilled cases.
 """
 import os
@@ -94,13 +95,33 @@ def main():
         verts, idx = T.reshape(-1, 3), np.arange(3 * len(T), dtype=np.uint32).reshape(len(T), 3)
         n = int(min(400000, max(20000, 4e9 / len(T) / 8)))
         org, d = rays(rng, T, n)
-        s = api.Scene(verts, idx, None, [api.make_material()])
-        s.set_lights([[0.0, 3.0, 0.0]])
+        # one or a few materials (one: shadow rays may stop at any blocker; several: they look for the closest)
+        nm = int(rng.choice([1, 1, 3]))
+        mats = [dict(ka=tuple(rng.uniform(0, .3, 3)), kd=tuple(rng.uniform(.2, .9, 3)), ks=tuple(rng.uniform(0, .8, 3)),
+                     ns=float(rng.uniform(2, 40)), d=1.0) for _ in range(nm)]
+        tri_mat = rng.integers(0, nm, len(T)).astype(np.int32)
+        ext = float(np.abs(T).max())
+        lights = [list(rng.uniform(-2, 2, 3) * ext) for _ in range(int(rng.integers(1, 3)))]
+        s = api.Scene(verts, idx, tri_mat, [api.make_material(**m) for m in mats])
+        s.set_lights(lights)
         s.commit(0)
         t, face = s.trace_closest(org, d)
         nwild = s.info().nwild
+        o_scene = oa.Scene(verts, idx, tri_mat, [oa.make_mtl(**m) for m in mats])
+        h = o_scene.closest(org, d, threads=16)
+        # ... and a small frame through the whole pipeline (camera rays, shadow rays, reflections)
+        res = 48
+        view = scenes.look_at_view(tuple(rng.uniform(-1, 1, 3) * 2.5 * ext + np.float64([0, 0, 0.5 * ext])), tuple(rng.uniform(-.2, .2, 3) * ext))
+        opts = (int(rng.integers(0, 3)), 1, 0, 0, 1, 0)
+        rgb, tt, ff = s.render(api.make_camera(view, res, res), api.Options(*opts), (0, 0, res, res))
         s.close()
-        h = oa.Scene(verts, idx, None, [oa.make_mtl()]).closest(org, d, threads=16)
+        o_scene.set_lights(lights)
+        o_scene.set_options(*opts)
+        orgb, ot, of = o_scene.render(oa.make_camera(view, res, res), (0, 0, res, res), threads=16)
+        rgb_bad = np.abs(rgb - orgb) > 1e-5 + 1e-4 * np.abs(orgb)
+        if not np.array_equal(ff, of) or not np.array_equal(tt.view(np.uint32), ot.view(np.uint32)) or rgb_bad.any():
+            print("seed %d: frame differs: %d face ids, %d rgb channels (options %r)" % (seed, int((ff != of).sum()), int(rgb_bad.sum()), opts))
+            sys.exit(1)
         bad = np.nonzero((face != h["face"]) | (t.view(np.uint32) != h["t"].view(np.uint32)))[0]
         print("seed %d: %6d triangles (%3d wild), %6d rays, %6d hits, %d differ" % (seed, len(T), nwild, len(org), int((h["face"] >= 0).sum()), len(bad)),
               flush=True)
