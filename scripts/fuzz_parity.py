@@ -5,8 +5,8 @@
 Random meshes (soups of several densities, thin triangles on both sides of the wild threshold, flat and
 duplicated faces, clusters at very different scales) x random rays (through points of triangles, their
 vertices and edges, the zone just past thin triangles, axis-parallel, from far away, from inside), hit ids
-and t compared bit for bit; plus a 48x48 frame through the whole pipeline (shadows, up to 2 reflections;
-one or several materials) against the oracle's render, ids and t bit for bit, RGB within 1e-4.  Prints one line per scene; exits 1 on the first difference (and says which
+and t compared bit for bit; plus a 48x48 frame through the whole pipeline (point and spherical lights,
+reflection and refraction trees up to 2 bounces, spheres, GI probes, one or several materials) against the oracle's render, ids and t bit for bit, RGB within 1e-4.  Prints one line per scene; exits 1 on the first difference (and says which
 seed, so that it can be replayed).  Needs a GPU; the tests hold the distilled cases.
 """
 import os
@@ -107,15 +107,41 @@ def main():
         s.commit(0)
         t, face = s.trace_closest(org, d)
         nwild = s.info().nwild
-        o_scene = oa.Scene(verts, idx, tri_mat, [oa.make_mtl(**m) for m in mats])
-        h = o_scene.closest(org, d, threads=16)
-        # ... and a small frame through the whole pipeline (camera rays, shadow rays, reflections)
+        h = oa.Scene(verts, idx, tri_mat, [oa.make_mtl(**m) for m in mats]).closest(org, d, threads=16)
+        s.close()
+        # ... and a small frame through the whole pipeline: camera rays, shadow rays (point and spherical lights),
+        # reflection / refraction trees, spheres, GI probes over the reference's leaf list where that list exists
         res = 48
         view = scenes.look_at_view(tuple(rng.uniform(-1, 1, 3) * 2.5 * ext + np.float64([0, 0, 0.5 * ext])), tuple(rng.uniform(-.2, .2, 3) * ext))
-        opts = (int(rng.integers(0, 3)), 1, 0, 0, 1, 0)
+        refl, refr = [(1, 0), (1, 0), (0, 1), (1, 1), (0, 0)][int(rng.integers(0, 5))]
+        gi = int(rng.choice([0, 0, 4]))
+        for m in mats:                          # refraction needs dissolve < 1 somewhere
+            m["d"] = float(rng.choice([1.0, 0.6])) if refr else 1.0
+            m["ni"] = float(rng.uniform(1.0, 1.6))
+        sph = rng.uniform(-1, 1, (int(rng.integers(0, 3)), 4)) * ext
+        if len(sph):
+            sph[:, 3] = rng.uniform(0.05, 0.3, len(sph)) * ext
+        sph_mat = rng.integers(0, nm, len(sph)).astype(np.int32)
+        slights = None
+        if rng.random() < 0.3:
+            slights = np.concatenate([rng.uniform(-2, 2, (1, 3)) * ext, [[0.1 * ext]]], 1)
+        s = api.Scene(verts, idx, tri_mat, [api.make_material(**m) for m in mats])
+        o_scene = oa.Scene(verts, idx, tri_mat, [oa.make_mtl(**m) for m in mats])
+        for sc in (s, o_scene):
+            sc.set_lights(lights, slights)
+            if len(sph):
+                sc.set_spheres(sph, sph_mat)
+        if gi:
+            try:
+                nl = s.build_reference_leafboxes()
+            except api.RtxError:                # the reference's split does not terminate on this mesh
+                gi = 0
+            else:
+                assert o_scene.build_leafboxes() == nl
+        opts = (int(rng.integers(0, 3)), refl, refr, gi, 1, 0)
+        s.commit(0)
         rgb, tt, ff = s.render(api.make_camera(view, res, res), api.Options(*opts), (0, 0, res, res))
         s.close()
-        o_scene.set_lights(lights)
         o_scene.set_options(*opts)
         orgb, ot, of = o_scene.render(oa.make_camera(view, res, res), (0, 0, res, res), threads=16)
         rgb_bad = np.abs(rgb - orgb) > 1e-5 + 1e-4 * np.abs(orgb)
