@@ -107,7 +107,17 @@ def main():
         s.commit(0)
         t, face = s.trace_closest(org, d)
         nwild = s.info().nwild
-        h = oa.Scene(verts, idx, tri_mat, [oa.make_mtl(**m) for m in mats]).closest(org, d, threads=16)
+        o_first = oa.Scene(verts, idx, tri_mat, [oa.make_mtl(**m) for m in mats])
+        h = o_first.closest(org, d, threads=16)
+        # canSeeLight between a light and surface points (a sample of the hit points above): flag and blocker material
+        hp = h["p"][h["face"] >= 0][:: max(1, int((h["face"] >= 0).sum()) // 4000)]
+        if len(hp):
+            lp = np.tile(np.float32(lights[0])[None], (len(hp), 1))
+            vis, bm = s.trace_visible(lp, hp)
+            ovis, obm, _, _ = o_first.visible(lp, hp)
+            if not (np.array_equal(vis, ovis) and np.array_equal(bm, obm)):
+                print("seed %d: canSeeLight differs on %d of %d points" % (seed, int(((vis != ovis) | (bm != obm)).sum()), len(hp)))
+                sys.exit(1)
         s.close()
         # ... and a small frame through the whole pipeline: camera rays, shadow rays (point and spherical lights),
         # reflection / refraction trees, spheres, GI probes over the reference's leaf list where that list exists
