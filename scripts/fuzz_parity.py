@@ -52,7 +52,10 @@ def mesh(rng):
         t = rng.uniform(-1, 1, (int(rng.integers(10, 200)), 3, 3))
         t[:, :, ax] = rng.uniform(-1, 1, (len(t), 1))
         parts.append(t)
-    T = np.concatenate(parts).astype(np.float32)
+    T = np.concatenate(parts)
+    if rng.random() < 0.3:
+        T = T * 10 ** rng.uniform(-3, 3) + rng.uniform(-1, 1, 3) * 10 ** rng.uniform(-2, 2)     # the whole scene tiny, huge or off-centre
+    T = T.astype(np.float32)
     if rng.random() < 0.5:
         T = np.concatenate([T, T[: max(1, len(T) // 20)][::-1]])          # duplicates: ties
     if rng.random() < 0.3:
