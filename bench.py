@@ -149,6 +149,8 @@ def main():
              "face": torch.full((npix_local, 1), -1, dtype=torch.int32, device=dev),
              "free": torch.cuda.Event()}
         b["acc"] = torch.zeros_like(b["rgb"]) if len(cams) > 1 else None
+        if world > 1 and rank == 0:
+            b["img"] = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
         if world > 1 and rank == 0 and not rehearse:
             b["g_rgb"] = torch.empty((world, npix_local, 3), dtype=torch.float32, device=dev)
         b["free"].record()
@@ -168,7 +170,10 @@ def main():
         else:
             g_rgb = tiles.gather_to_root(out, world, rank, dist, b.get("g_rgb"))
         if rank == 0:
-            return (tiles.assemble(g_rgb, W, H, TILE, 3), None)
+            # one pass back to row-major (rtx_tiles_assemble_dev on torch's stream; tiles.assemble is its torch twin)
+            api.tiles_assemble_dev(g_rgb.data_ptr(), world, g_rgb.shape[1], rect, TILE, 3, b["img"].data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream)
+            return (b["img"], None)
         return None
 
     def frame():

@@ -235,6 +235,14 @@ int rtx_render_tiles_dev_enqueue(rtx_scene*, const rtx_camera*, const rtx_option
                                  int32_t tile_size, int32_t part, int32_t nparts,
                                  float* rgb, float* t, int32_t* face_id);
 
+/* The inverse of that layout, for the rank that collects the parts: `parts` holds the compact buffers of
+ * parts 0 .. nparts-1 one after the other, part_stride_pixels apart (>= rtx_tiles_count(rect, tile_size, 0,
+ * nparts) * tile_size^2), words_per_pixel 32-bit words per pixel (3 for rgb, 1 for t or face_id);
+ * out receives the row-major rectangle [y - y0][x - x0].  Device pointers; runs on `stream` (a
+ * hipStream_t as void*, NULL = default stream) and returns without waiting for it.  No scene needed. */
+int rtx_tiles_assemble_dev(const void* parts, int32_t nparts, uint64_t part_stride_pixels, rtx_rect rect,
+                           int32_t tile_size, int32_t words_per_pixel, void* out, void* stream);
+
 int rtx_get_stats(const rtx_scene*, rtx_stats*);
 
 #ifdef __cplusplus

@@ -49,7 +49,7 @@ SYMBOLS = ["rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_
            "rtx_scene_add_material", "rtx_scene_set_spheres", "rtx_scene_set_lights", "rtx_scene_build", "rtx_scene_commit",
            "rtx_scene_get_tris",
            "rtx_scene_get_info", "rtx_scene_get_bvh", "rtx_trace_closest", "rtx_trace_closest_dev",
-           "rtx_trace_visible", "rtx_render", "rtx_render_dev", "rtx_render_dev_enqueue", "rtx_render_finish", "rtx_tiles_count", "rtx_render_tiles_dev", "rtx_render_tiles_dev_enqueue",
+           "rtx_trace_visible", "rtx_render", "rtx_render_dev", "rtx_render_dev_enqueue", "rtx_render_finish", "rtx_tiles_count", "rtx_render_tiles_dev", "rtx_render_tiles_dev_enqueue", "rtx_tiles_assemble_dev",
            "rtx_get_stats", "rtx_scene_build_reference_leafboxes", "rtx_scene_set_leafboxes",
            "rtx_scene_get_leafboxes", "rtx_intersect_box", "rtx_trace_shade", "rtx_camera_points", "rtx_scene_set_flags",
            "rtx_scene_get_packed_bvh", "rtx_debug_hit"]
@@ -123,6 +123,7 @@ def lib():
                                            C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rtx_render_tiles_dev_enqueue.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Options), Rect, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rtx_tiles_assemble_dev.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, Rect, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -355,3 +356,10 @@ class Scene:
         s = Stats()
         _check(lib().rtx_get_stats(self.h, C.byref(s)))
         return s
+
+
+def tiles_assemble_dev(parts_ptr, nparts, part_stride_pixels, rect, tile_size, words_per_pixel, out_ptr, stream=None):
+    """rtx_tiles_assemble_dev: compact tile buffers of all parts -> row-major rectangle, on `stream` (no wait)."""
+    x0, y0, x1, y1 = rect
+    _check(lib().rtx_tiles_assemble_dev(parts_ptr, nparts, part_stride_pixels, Rect(x0, y0, x1, y1), tile_size,
+                                        words_per_pixel, out_ptr, stream))

@@ -958,6 +958,34 @@ extern "C" int rtx_tiles_count(rtx_rect rect, int32_t tile_size, int32_t part, i
   return (int)((total - part + nparts - 1) / nparts);
 }
 
+// rtx_render_tiles_dev's layout undone: the compact tile buffers of all parts (one after the other,
+// part_stride_pixels apart) -> the row-major rectangle.  Stateless; runs on `stream` (a hipStream_t, may be
+// null for the default stream) and does not wait for it.
+extern "C" int rtx_tiles_assemble_dev(const void* parts, int32_t nparts, uint64_t part_stride_pixels, rtx_rect rect, int32_t tile_size,
+                                      int32_t words_per_pixel, void* out, void* stream) {
+  if (!parts || !out) return fail(RTX_EINVAL, "null buffer");
+  if (words_per_pixel < 1 || words_per_pixel > 16) return fail(RTX_EINVAL, "words_per_pixel must be in [1,16]");
+  const int kmax = rtx_tiles_count(rect, tile_size, 0, nparts);      // validates rect / tile_size / nparts
+  if (kmax < 0) return kmax;
+  if (part_stride_pixels < (uint64_t)kmax * tile_size * tile_size) return fail(RTX_EINVAL, "part_stride_pixels smaller than a part");
+  const uint32_t w = (uint32_t)(rect.x1 - rect.x0), h = (uint32_t)(rect.y1 - rect.y0);
+  if ((uint64_t)w * h >= (1ull << 31)) return fail(RTX_ELIMIT, "rectangle has too many pixels");
+  const uint64_t n = (uint64_t)w * h * (uint32_t)words_per_pixel;
+  const bool aligned16 = (((uintptr_t)parts | (uintptr_t)out) & 15u) == 0 && ((part_stride_pixels * (uint32_t)words_per_pixel) & 3u) == 0;
+  if ((w & 3u) == 0 && aligned16) {
+    const uint32_t grid4 = (uint32_t)std::min<uint64_t>((n / 4 + 255) / 256, 256u * 64u);
+    hipLaunchKernelGGL(k_assemble_tiles_v4, dim3(grid4), dim3(256), 0, (hipStream_t)stream, (const uint4*)parts, (uint32_t)nparts,
+                       part_stride_pixels * (uint32_t)words_per_pixel / 4, w, h, (uint32_t)tile_size, (uint32_t)words_per_pixel, (uint4*)out);
+    HIP_TRY(hipGetLastError());
+    return RTX_OK;
+  }
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256u * 64u);
+  hipLaunchKernelGGL(k_assemble_tiles, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)parts, (uint32_t)nparts,
+                     part_stride_pixels * (uint32_t)words_per_pixel, w, h, (uint32_t)tile_size, (uint32_t)words_per_pixel, (uint32_t*)out);
+  HIP_TRY(hipGetLastError());
+  return RTX_OK;
+}
+
 static int render_tiles_impl(rtx_scene* s, const rtx_camera* cam, const rtx_options* opt, rtx_rect rect, int32_t tile_size,
                              int32_t part, int32_t nparts, float* rgb, float* t, int32_t* face, bool wait) {
   if (int rc = check_ready(s)) return rc;

@@ -652,6 +652,41 @@ __global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_tra
   }
 }
 
+// The inverse of the tiled-compact layout: parts[p][k * ts * ts + (y % ts) * ts + (x % ts)][c] of every
+// part p -> out[y][x][c]; tile g = (y / ts) * tiles_x + (x / ts) is local tile g / nparts of part g % nparts.
+// One 32-bit word per thread: consecutive threads read and write consecutive words within a tile row.
+__global__ void k_assemble_tiles(const uint32_t* parts, uint32_t nparts, uint64_t part_stride_words, uint32_t w, uint32_t h,
+                                 uint32_t ts, uint32_t words, uint32_t* out) {
+  const uint64_t n = (uint64_t)w * h * words;
+  const uint32_t tiles_x = (w + ts - 1) / ts;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t pix = (uint32_t)(i / words), c = (uint32_t)(i - (uint64_t)pix * words);
+    const uint32_t y = pix / w, x = pix - y * w;
+    const uint32_t g = (y / ts) * tiles_x + (x / ts);
+    const uint32_t p = g % nparts, k = g / nparts;
+    const uint64_t src = (uint64_t)p * part_stride_words + ((uint64_t)k * ts * ts + (uint64_t)(y % ts) * ts + (x % ts)) * words + c;
+    out[i] = parts[src];
+  }
+}
+
+// The same, 16 bytes per thread, for widths that are multiples of 4 pixels (every tile row then is a whole
+// number of 16-byte pieces, aligned in both buffers because tile sizes are multiples of 16 pixels).
+// Thread -> (row y, piece q of that row); a row has w * words / 4 pieces.
+__global__ void k_assemble_tiles_v4(const uint4* parts, uint32_t nparts, uint64_t part_stride_v4, uint32_t w, uint32_t h,
+                                    uint32_t ts, uint32_t words, uint4* out) {
+  const uint32_t row_v4 = w * words / 4u, tile_v4 = ts * words / 4u;      // pieces per image row / per full tile row
+  const uint32_t tiles_x = (w + ts - 1) / ts;
+  const uint64_t n = (uint64_t)row_v4 * h;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t y = (uint32_t)(i / row_v4), q = (uint32_t)(i - (uint64_t)y * row_v4);
+    const uint32_t tx = q / tile_v4, r = q - tx * tile_v4;               // tile column, piece within the tile's row
+    const uint32_t g = (y / ts) * tiles_x + tx;
+    const uint32_t p = g % nparts, k = g / nparts;
+    const uint64_t src = (uint64_t)p * part_stride_v4 + ((uint64_t)k * ts + (y % ts)) * tile_v4 + r;
+    out[i] = parts[src];
+  }
+}
+
 // Ray ctor over caller rays (src/Ray.h:15-18): xyz arrays -> queue records.
 __global__ void k_make_rays(const float* o, const float* d, uint32_t n, float4* rays) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
