@@ -27,7 +27,11 @@ def mesh(rng):
     parts = []
     kind = rng.integers(0, 4)
     if kind == 0:      # a soup
-        v, i = scenes.soup(int(rng.integers(500, 20000)), seed=int(rng.integers(1, 1 << 30)), h=float(10 ** rng.uniform(-2.2, -0.7)))
+        # (one in four: triangles as large as the scene, so that every box overlaps every other and the per-lane
+        # stacks grow past their LDS part into the global overflow columns)
+        fat = rng.random() < 0.25
+        v, i = scenes.soup(int(rng.integers(4000, 40000) if fat else rng.integers(500, 20000)), seed=int(rng.integers(1, 1 << 30)),
+                           h=float(rng.uniform(0.3, 1.0) if fat else 10 ** rng.uniform(-2.2, -0.7)))
         parts.append(v[i.astype(np.int64)].reshape(-1, 3, 3))
     elif kind == 1:    # clusters at different scales
         for _ in range(int(rng.integers(2, 6))):
