@@ -432,11 +432,15 @@ struct QueueSource {
 //    are parked in a small per-wave LDS buffer (wbuf, 9 words x 64);
 //  * lanes whose ray has finished take a parked ray (refill) once kRefillMin lanes are idle,
 //    instead of idling until the slowest ray of a 64-ray group is done;
-//  * a lane that reaches a leaf waits until kDeferMin lanes are at leaves (or no lane has a
-//    node to do), so that the expensive triangle tests run with more lanes active.
-// None of this changes what is computed per ray: each ray still sees its nodes and triangles
-// in the same order; scripts/wave_sim.py replays traversal logs under these policies.
-constexpr uint32_t kDone = 0x7FFFFFFFu;   // lane holds no ray (never a valid entry: group indices stay below 2^25)
+//  * triangle tests run in leaf phases, one triangle per lane and pass, when kDeferMin lanes hold a
+//    leaf (or kBlockMin hold one and have nothing else to do, or no lane has node work); a lane
+//    that reaches a leaf in between keeps it in a one-entry pending slot and goes on with its
+//    next stack entry, so that the expensive tests run with more lanes active and the node steps
+//    with fewer lanes waiting.
+// None of this changes a ray's result: every triangle whose box the ray enters before its final hit
+// distance is still tested, only later (closest hits are order independent: (t, faceId) minimum);
+// scripts/wave_replay.py replays real traversals under these policies on the CPU.
+constexpr uint32_t kDone = 0x7FFFFFFFu;   // lane holds no ray (never a valid entry: group indices stay below 2^26)
 constexpr int kRefillMin = RTX_REFILL_MIN;
 constexpr int kDeferMin = RTX_DEFER_MIN;
 constexpr int kBlockMin = RTX_BLOCK_MIN;
