@@ -533,6 +533,23 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
     for (size_t i = 0; uniform && i < s->sph_mat.size(); ++i) uniform = s->sph_mat[i] >= 0 && s->sph_mat[i] < nm;
     if (uniform) d.flags |= 2u;
   }
+  // skip_zero_weight asks, per hit, whether the material's reflection weight (1 - d) or refraction weight
+  // (d) is exactly zero.  Where every dissolve value in use answers alike the kernels need not look the
+  // material up: bit 2 no material reflects, bit 3 every one does, bit 4 none refracts, bit 5 every one does.
+  {
+    const int nm = (int)s->mats.size();
+    bool use_default = false;                      // some face or sphere falls back to Mtl(): d = 1
+    for (size_t i = 0; !use_default && i < s->tri_mat.size(); ++i) use_default = s->tri_mat[i] < 0 || s->tri_mat[i] >= nm;
+    for (size_t i = 0; !use_default && i < s->sph_mat.size(); ++i) use_default = s->sph_mat[i] < 0 || s->sph_mat[i] >= nm;
+    int n_all = 0, n_norefl = 0, n_norefr = 0;
+    auto tally = [&](float dd) { ++n_all; n_norefl += (1.0f - dd == 0.0f); n_norefr += (dd == 0.0f); };
+    for (const rtx_material& m : s->mats) tally(m.d);          // (records no face uses are counted too: conservative)
+    if (use_default) tally(1.0f);
+    if (n_all) {
+      if (n_norefl == n_all) d.flags |= 4u; else if (n_norefl == 0) d.flags |= 8u;
+      if (n_norefr == n_all) d.flags |= 16u; else if (n_norefr == 0) d.flags |= 32u;
+    }
+  }
   d.ntris = ntris; d.nwild = s->nwild; d.nspheres = (uint32_t)(s->spheres.size() / 4); d.nlights = (uint32_t)(s->lights.size() / 3);
   d.nmats = (uint32_t)s->mats.size();
   for (int k = 0; k < 3; ++k) { d.root_lo[k] = s->root_lo[k]; d.root_hi[k] = s->root_hi[k]; }

@@ -60,7 +60,8 @@ struct DevScene {
   const int* face_pos;     // mesh face id -> position in tris
   uint32_t ntris, nspheres, nlights, nmats;
   uint32_t nsl, nleafboxes;
-  uint32_t flags, pad1;           // bit 0: skip the reference's root-box gate (intersectTriangle semantics)
+  uint32_t flags, pad1;           // bit 0: skip the reference's root-box gate (intersectTriangle semantics); bit 1: any blocker
+                                  // shades alike; bits 2-5: reflection / refraction weights zero for all or for no material (rtx.hip)
                                   // bit 1: every material shades a blocked light alike (set at commit)
   float root_lo[3], root_hi[3];   // Box(mesh) of the reference, used as its root gate
   uint32_t root_entry;            // traversal entry of the BVH root
@@ -909,10 +910,17 @@ __device__ __forceinline__ Spawn classify(const PipeArgs& A, uint32_t i) {
   if (sp.hit && A.bounce < A.max_bounces) {
     sp.refl = A.reflection != 0; sp.refr = A.refraction != 0;
     if (A.skip_zero_weight && (sp.refl || sp.refr)) {
-      const int m = sp.id >= 0 ? __float_as_int(A.S.face_nm[sp.id].w) : A.S.sph_mat[-2 - sp.id];
-      const float d = (m < 0 || m >= (int)A.S.nmats) ? 1.0f : A.S.mats[m].d;      // default Mtl: d = 1
-      if (1.0f - d == 0.0f) sp.refl = false;
-      if (d == 0.0f) sp.refr = false;
+      // where all materials in use answer alike (DevScene.flags bits 2-5, set at commit) no lookup is needed
+      const uint32_t f = A.S.flags;
+      if (f & 4u) sp.refl = false;
+      if (f & 16u) sp.refr = false;
+      const bool ask = (sp.refl && !(f & 8u)) || (sp.refr && !(f & 32u));
+      if (ask) {
+        const int m = sp.id >= 0 ? __float_as_int(A.S.face_nm[sp.id].w) : A.S.sph_mat[-2 - sp.id];
+        const float d = (m < 0 || m >= (int)A.S.nmats) ? 1.0f : A.S.mats[m].d;      // default Mtl: d = 1
+        if (1.0f - d == 0.0f) sp.refl = false;
+        if (d == 0.0f) sp.refr = false;
+      }
     }
   }
   return sp;

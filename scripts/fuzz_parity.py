@@ -132,8 +132,8 @@ def main():
         view = scenes.look_at_view(tuple(rng.uniform(-1, 1, 3) * 2.5 * ext + np.float64([0, 0, 0.5 * ext])), tuple(rng.uniform(-.2, .2, 3) * ext))
         refl, refr = [(1, 0), (1, 0), (0, 1), (1, 1), (0, 0)][int(rng.integers(0, 5))]
         gi = int(rng.choice([0, 0, 4]))
-        for m in mats:                          # refraction needs dissolve < 1 somewhere
-            m["d"] = float(rng.choice([1.0, 0.6])) if refr else 1.0
+        for m in mats:                          # dissolve: 1 = no reflection weight, 0 = no refraction weight, or in between
+            m["d"] = float(rng.choice([1.0, 0.6, 0.0, 1.0]))
             m["ni"] = float(rng.uniform(1.0, 1.6))
         sph = rng.uniform(-1, 1, (int(rng.integers(0, 3)), 4)) * ext
         if len(sph):
@@ -155,7 +155,7 @@ def main():
                 gi = 0
             else:
                 assert o_scene.build_leafboxes() == nl
-        opts = (int(rng.integers(0, 3)), refl, refr, gi, 1, 0)
+        opts = (int(rng.integers(0, 3)), refl, refr, gi, 1, int(rng.integers(0, 2)))     # the last: do not trace children of weight 0
         s.commit(0)
         rgb, tt, ff = s.render(api.make_camera(view, res, res), api.Options(*opts), (0, 0, res, res))
         s.close()

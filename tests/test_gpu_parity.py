@@ -607,6 +607,35 @@ def test_refill_scheduler_camera_kernel_on_a_large_frame(api, oa):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dvals", [(1.0, 1.0), (0.5, 0.5), (1.0, 0.4), (0.0, 0.3), (0.0, 0.0)])
+def test_skipping_zero_weight_children_changes_nothing(api, oa, dvals):
+    """skip_zero_weight (what bench.py runs with) only leaves out child rays whose blend weight is exactly 0:
+    the frame must equal the one with every child traced, and the oracle's, for materials whose dissolve
+    makes the reflection weight (1 - d) or the refraction weight (d) vanish everywhere, nowhere, or on some."""
+    fx = load_scene_fixture("twoObjects")
+    mats = [dict(ka=(.1, .1, .1), kd=(.6, .5, .4), ks=(.5, .5, .5), ns=20.0, ni=1.3, d=dvals[0]),
+            dict(ka=(.1, .1, .1), kd=(.3, .6, .7), ks=(.2, .2, .2), ns=8.0, ni=1.1, d=dvals[1])]
+    tri_mat = (np.arange(len(fx["idx"])) % 2).astype(np.int32)
+    s = api.Scene(fx["verts"], fx["idx"], tri_mat, [api.make_material(**m) for m in mats])
+    s.set_lights([[-1.0, 1.0, 1.0], [1.5, 2.0, 0.5]])
+    s.commit(0)
+    o = oa.Scene(fx["verts"], fx["idx"], tri_mat, [oa.make_mtl(**m) for m in mats])
+    o.set_lights([[-1.0, 1.0, 1.0], [1.5, 2.0, 0.5]])
+    res = 64
+    for refl, refr in ((1, 0), (1, 1), (0, 1)):
+        cam = api.make_camera(fx["view_oblique"], res, res)
+        full = s.render(cam, api.Options(2, refl, refr, 0, 1, 0), (0, 0, res, res))
+        skip = s.render(cam, api.Options(2, refl, refr, 0, 1, 1), (0, 0, res, res))
+        assert np.array_equal(full[2], skip[2])
+        assert_bits_equal(skip[0], full[0], "rgb with and without the weight-0 children (%d, %d)" % (refl, refr))
+        o.set_options(2, refl, refr, 0, 1, 1)
+        orgb, ot, of = o.render(oa.make_camera(fx["view_oblique"], res, res), (0, 0, res, res), threads=16)
+        assert np.array_equal(skip[2], of)
+        assert_rgb_close(skip[0], orgb, "rgb vs oracle (%d, %d)" % (refl, refr))
+    s.close()
+
+
+@pytest.mark.gpu
 def test_frames_stay_identical_while_the_scheduler_is_tuned(api):
     """The library times its scheduler modes on the first seven render calls of a scene (one
     untimed, then groups / refill / split twice each) and keeps one per launch kind: every one of
