@@ -5,6 +5,7 @@ reference arithmetic; shaded RGB within 1e-4 relative.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -770,6 +771,28 @@ def test_nasty_geometry_random_rays_vs_bruteforce(api, oa):
     assert_bits_equal(tt, ot, "t (render)")
     assert_rgb_close(rgb, orgb, "nasty render")
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 7, 1003, 5005, 20007, 30001, 100003])
+def test_fuzzer_scenes(api, oa, seed):
+    """A few scenes of scripts/fuzz_parity.py (random meshes x random rays, see there) at reduced ray counts,
+    so that the suite itself keeps exercising what the long fuzzing runs covered."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import fuzz_parity
+    rng = np.random.default_rng(seed)
+    T = fuzz_parity.mesh(rng)
+    verts, idx = T.reshape(-1, 3), np.arange(3 * len(T), dtype=np.uint32).reshape(len(T), 3)
+    org, d = fuzz_parity.rays(rng, T, int(min(40000, max(8000, 2e8 / len(T)))))
+    s = api.Scene(verts, idx, None, [api.make_material()])
+    s.set_lights([[0.0, 3.0, 0.0]])
+    s.commit(0)
+    t, face = s.trace_closest(org, d)
+    s.close()
+    h = oa.Scene(verts, idx, None, [oa.make_mtl()]).closest(org, d, threads=16)
+    assert (h["face"] >= 0).sum() > len(org) // 10
+    assert np.array_equal(face, h["face"])
+    assert_bits_equal(t, h["t"], "t")
 
 
 @pytest.mark.gpu
