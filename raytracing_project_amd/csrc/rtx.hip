@@ -957,7 +957,9 @@ extern "C" int rtx_render_dev_enqueue(rtx_scene* s, const rtx_camera* cam, const
   return render_impl(s, C, npix, tiles, opt, rgb, t, face, false);
 }
 extern "C" int rtx_render_finish(rtx_scene* s, rtx_stats* out) {
-  if (int rc = check_ready(s)) return rc;
+  if (!s) return fail(RTX_EINVAL, "null scene");
+  if (s->device < 0) return fail(RTX_ESTATE, "no enqueued render call to finish");
+  HIP_TRY(hipSetDevice(s->device));          // (a scene changed after the enqueue can still finish what it started)
   rtx_scene::Call& older = s->calls[s->cur ^ 1];
   rtx_scene::Call& c = older.pending ? older : cur_call(s);
   if (!c.pending) return fail(RTX_ESTATE, "no enqueued render call to finish");
