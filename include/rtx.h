@@ -71,7 +71,8 @@ typedef struct { int32_t x0, y0, x1, y1; } rtx_rect;   /* pixel rectangle [x0,x1
 /* Counters of the last trace/render call on a scene. */
 typedef struct {
   uint64_t rays_primary, rays_shadow, rays_reflection, rays_refraction, rays_gi;
-  float ms_trace;      /* HIP-event time of the traversal kernels (sum over launches) */
+  float ms_trace;      /* HIP-event time of the traversal kernels, summed over launches (a render with bounces runs the
+                          bounce launch of a generation beside its shadow launch: both spans count in full) */
   float ms_total;      /* HIP-event time of every kernel of the call */
   uint32_t launches_trace;
   float ms_trace_camera;   /* the primary-ray traversal launch alone (0 when the call had none) */

@@ -87,6 +87,7 @@ struct rtx_scene {
   bool committed = false;
   int device = -1;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;     // bounce launches that overlap the shadow launch of the same generation (run_pipeline)
   BvhBuildResult bvh;
   DevScene dev{};
   DevBuf d_nodes, d_tris, d_tri_face, d_face_nm, d_spheres, d_sph_mat, d_mats, d_lights;
@@ -96,7 +97,8 @@ struct rtx_scene {
   DevCamera cam_tab_of{};            // the camera w_cam_tab currently holds the tables of (valid: cam_tab_ok)
   bool cam_tab_ok = false;
   DevBuf w_stack_ovf;                // global overflow columns of the per-lane traversal stacks
-  DevBuf w_rays[2], w_hits[2], w_parents, w_shadow_rays, w_shadow_hits, w_gi_rays, w_gi_hits, w_counters, w_io[6];
+  DevBuf w_stack_ovf2;               // ... of the launches on stream2 (they run beside launches on `stream`)
+  DevBuf w_rays[2], w_hits[3], w_parents, w_shadow_rays, w_shadow_hits, w_gi_rays, w_gi_hits, w_counters, w_io[6];
   // Per-call bookkeeping.  Two of them, so that a render call can be enqueued while the one before is
   // still running (rtx_render_dev_enqueue / rtx_render_finish); every other entry point begins and
   // finishes its call in one go.
@@ -164,10 +166,11 @@ static void release_device(rtx_scene* s) {
   if (s->device >= 0) (void)hipSetDevice(s->device);
   DevBuf* bufs[] = {&s->d_nodes, &s->d_tris, &s->d_tri_face, &s->d_face_nm, &s->d_spheres, &s->d_sph_mat, &s->d_mats,
                     &s->d_lights, &s->d_slights, &s->d_leafboxes, &s->d_leaf_faces, &s->d_face_pos, &s->w_gi_rays,
-                    &s->w_gi_hits, &s->w_stack_ovf, &s->w_cam_tab, &s->w_rays[0], &s->w_rays[1], &s->w_hits[0], &s->w_hits[1], &s->w_parents,
+                    &s->w_gi_hits, &s->w_stack_ovf, &s->w_cam_tab, &s->w_rays[0], &s->w_rays[1], &s->w_hits[0], &s->w_hits[1], &s->w_hits[2], &s->w_stack_ovf2, &s->w_parents,
                     &s->w_shadow_rays, &s->w_shadow_hits, &s->w_counters, &s->w_io[0], &s->w_io[1], &s->w_io[2],
                     &s->w_io[3], &s->w_io[4], &s->w_io[5]};
   if (s->stream) (void)hipStreamSynchronize(s->stream);      // calls still in flight
+  if (s->stream2) (void)hipStreamSynchronize(s->stream2);
   for (DevBuf* b : bufs) b->release();
   s->cam_tab_ok = false;
   for (rtx_scene::Call& c : s->calls) {
@@ -176,6 +179,7 @@ static void release_device(rtx_scene* s) {
     c.hc = nullptr; c.hc_words = 0; c.pending = false;
   }
   if (s->stream) { (void)hipStreamDestroy(s->stream); s->stream = nullptr; }
+  if (s->stream2) { (void)hipStreamDestroy(s->stream2); s->stream2 = nullptr; }
   s->committed = false;
 }
 
@@ -443,11 +447,13 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   HIP_TRY(hipSetDevice(device));
   s->device = device;
   if (!s->stream) HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  if (!s->stream2) HIP_TRY(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   s->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (int rc = rtx_scene_build(s)) return rc;
   if (int rc = s->w_stack_ovf.ensure((size_t)trace_grid(s) * kBlock * (kStackDepth - kLdsStack) * 4)) return rc;
+  if (int rc = s->w_stack_ovf2.ensure((size_t)trace_grid(s) * kBlock * (kStackDepth - kLdsStack) * 4)) return rc;
   const uint32_t ntris = (uint32_t)s->tri_mat.size();
   const std::vector<float4>& tri_leaf = s->h_tri_leaf;
   const std::vector<int32_t>& tri_face = s->h_tri_face;
@@ -601,16 +607,16 @@ static int grid_for(const rtx_scene* s, size_t items) {
   size_t cap = (size_t)s->ncu * 8;
   return (int)std::max<size_t>(1, std::min(blocks, cap));
 }
-static void span_begin(rtx_scene* s, bool trace) {
+static void span_begin(rtx_scene* s, bool trace, hipStream_t on = nullptr) {
   rtx_scene::Call& c = cur_call(s);
   hipEvent_t a = c.events.get(), b = c.events.get();
-  (void)hipEventRecord(a, s->stream);
+  (void)hipEventRecord(a, on ? on : s->stream);
   (trace ? c.trace_spans : c.all_spans).push_back({a, b});
   if (trace) c.span_kind.push_back(-1);
 }
-static void span_end(rtx_scene* s, bool trace) {
+static void span_end(rtx_scene* s, bool trace, hipStream_t on = nullptr) {
   rtx_scene::Call& c = cur_call(s);
-  (void)hipEventRecord((trace ? c.trace_spans : c.all_spans).back().second, s->stream);
+  (void)hipEventRecord((trace ? c.trace_spans : c.all_spans).back().second, on ? on : s->stream);
 }
 static void tune_update(rtx_scene* s, rtx_scene::Call& c);
 // Waits for an enqueued call, turns its events and counters into rtx_stats, feeds the tuner.
@@ -776,6 +782,15 @@ static void tune_update(rtx_scene* s, rtx_scene::Call& c) {
     }
   }
 }
+// Overlapped bounce launches (run_pipeline): RTX_OVERLAP=0 never, =1 always; by default once the tuner has
+// settled the shadow and the bounce queue of this scene (its trial frames time one launch at a time).
+static bool overlap_launches(const rtx_scene* s) {
+  static const int forced = [] { const char* e = std::getenv("RTX_OVERLAP"); return e ? std::atoi(e) : -1; }();
+  if (forced == 0) return false;
+  if (forced > 0) return true;
+  if ((s->flags & (RTX_FLAG_SCHED_REFILL | RTX_FLAG_SCHED_GROUPS)) || sched_forced() >= 0) return true;
+  return s->tune[KIND_SHADOW].choice >= 0 && s->tune[KIND_BOUNCE].choice >= 0;
+}
 static int launch_trace_camera(rtx_scene* s, const DevCamera& C, uint32_t tiles, uint2* hits) {
   const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(tiles, 1), (uint32_t)trace_grid(s));
   const uint32_t grid_r = std::min<uint32_t>(grid, (uint32_t)s->ncu * RTX_BLOCKS_REFILL);
@@ -789,18 +804,20 @@ static int launch_trace_camera(rtx_scene* s, const DevCamera& C, uint32_t tiles,
   return RTX_OK;
 }
 static int launch_trace_queue(rtx_scene* s, const float4* rays, const uint32_t* count, uint32_t stride, uint64_t bound, uint2* hits,
-                              bool shadow = false, bool any_blocker = false) {
+                              bool shadow = false, bool any_blocker = false, bool side = false) {
+  hipStream_t on = side ? s->stream2 : s->stream;                        // side launches have their own overflow columns
+  uint32_t* ovf = (side ? s->w_stack_ovf2 : s->w_stack_ovf).as<uint32_t>();
   const uint64_t blocks = (bound * stride + kBlock - 1) / kBlock;
   const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, (uint64_t)trace_grid(s)));
   const uint32_t grid_r = std::min<uint32_t>(grid, (uint32_t)s->ncu * RTX_BLOCKS_REFILL);
   const int mode = sched_pick(s, shadow ? KIND_SHADOW : KIND_BOUNCE, bound * stride);
   const uint32_t bounded = shadow ? (any_blocker ? 3u : 1u) : 0u;
   if (mode != SCHED_GROUPS)
-    hipLaunchKernelGGL(k_trace_queue<true>, dim3(grid_r), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride, bounded, grab_size(),
-                       mode == SCHED_REFILL_SPLIT ? kTriMinSplit : 1u, s->w_stack_ovf.as<uint32_t>(), hits);
+    hipLaunchKernelGGL(k_trace_queue<true>, dim3(grid_r), dim3(kBlock), 0, on, s->dev, rays, count, stride, bounded, grab_size(),
+                       mode == SCHED_REFILL_SPLIT ? kTriMinSplit : 1u, ovf, hits);
   else
-    hipLaunchKernelGGL(k_trace_queue<false>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, rays, count, stride, bounded, grab_size(), 1u,
-                       s->w_stack_ovf.as<uint32_t>(), hits);
+    hipLaunchKernelGGL(k_trace_queue<false>, dim3(grid), dim3(kBlock), 0, on, s->dev, rays, count, stride, bounded, grab_size(), 1u,
+                       ovf, hits);
   return RTX_OK;
 }
 
@@ -1065,6 +1082,7 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
       if (int rc = s->w_rays[0].ensure((size_t)max_nodes * 32)) return rc;
       if (int rc = s->w_rays[1].ensure((size_t)max_nodes * 32)) return rc;
       if (int rc = s->w_hits[1].ensure((size_t)max_nodes * 8)) return rc;
+      if (max_gen > 1) { if (int rc = s->w_hits[2].ensure((size_t)max_nodes * 8)) return rc; }
     }
   }
   // counters: per generation g, [4g] = #parents, [4g+1] = #nodes of generation g+1, [4g+2] = #refraction rays spawned
@@ -1086,6 +1104,7 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
   const float th_gi = G ? (float)(M_PI * 2 / (double)G) : 0.0f;      // Ray::resendRay: float theta = M_PI * 2 / n
   const float th_sl = (float)(M_PI * 2 / 4);                          // Shader::getNPointsOnCircle with n = 4
   uint64_t bound = pr.n0;                                             // host-side upper bound of the node count
+  const bool overlap = max_gen > 0 && shade && overlap_launches(s);
   for (int g = 0; g <= max_gen; ++g) {
     const int cur = g & 1, nxt = cur ^ 1;
     PipeArgs A;
@@ -1095,7 +1114,10 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
     A.n0 = pr.n0;
     A.nrays = g == 0 ? nullptr : cnt + 4 * (g - 1) + 1;
     A.rays = (pr.camera && g == 0) ? nullptr : s->w_rays[cur].as<float4>();
-    A.hits = (g == 0 ? s->w_hits[0] : s->w_hits[1]).as<uint2>();
+    // hits of generation g: [0] for the first, then [1] and [2] in turn (the trace of generation g+1 may run while
+    // k_resolve still reads those of g)
+    A.hits = s->w_hits[g == 0 ? 0 : 1 + ((g - 1) & 1)].as<uint2>();
+    uint2* hits_next = s->w_hits[1 + (g & 1)].as<uint2>();
     A.rgb = rgb; A.out_t = t; A.out_face = face;
     A.parents = s->w_parents.as<uint32_t>();
     A.shadow_rays = s->w_shadow_rays.as<float4>(); A.shadow_hits = s->w_shadow_hits.as<uint2>();
@@ -1105,6 +1127,23 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
     A.gi_sin = sinf(th_gi); A.gi_cos = cosf(th_gi); A.sl_sin = sinf(th_sl); A.sl_cos = cosf(th_sl);
     hipLaunchKernelGGL(k_shade, dim3(grid_for(s, bound)), dim3(kBlock), 0, s->stream, A);
     if (!shade) break;
+    // The bounce rays of generation g+1 and the shadow rays of g both come out of k_shade and do not depend on
+    // each other: with overlap on, the bounce launch goes to stream2 and fills the CUs that the shadow launch
+    // leaves as its last waves drain (and the other way round); the main stream takes the result up again
+    // before the next k_shade.
+    const uint64_t bound_next = tree ? bound * 2 : bound;
+    hipEvent_t side_done = nullptr;
+    if (overlap && g < max_gen) {
+      rtx_scene::Call& cc = cur_call(s);
+      hipEvent_t shaded = cc.events.get();
+      side_done = cc.events.get();
+      HIP_TRY(hipEventRecord(shaded, s->stream));
+      HIP_TRY(hipStreamWaitEvent(s->stream2, shaded, 0));
+      span_begin(s, true, s->stream2);
+      if (int rc = launch_trace_queue(s, s->w_rays[nxt].as<float4>(), cnt + 4 * g + 1, 1u, bound_next, hits_next, false, false, true)) return rc;
+      span_end(s, true, s->stream2);
+      HIP_TRY(hipEventRecord(side_done, s->stream2));
+    }
     if (opt->shadows && NLS) {
       span_begin(s, true);
       if (int rc = launch_trace_queue(s, s->w_shadow_rays.as<float4>(), cnt + 4 * g, NLS, bound, s->w_shadow_hits.as<uint2>(), true, true)) return rc;
@@ -1118,10 +1157,14 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
     }
     hipLaunchKernelGGL(k_resolve, dim3(grid_for(s, bound)), dim3(kBlock), 0, s->stream, A);
     if (g < max_gen) {
-      if (tree) bound *= 2;
-      span_begin(s, true);
-      if (int rc = launch_trace_queue(s, s->w_rays[nxt].as<float4>(), cnt + 4 * g + 1, 1u, bound, s->w_hits[1].as<uint2>())) return rc;
-      span_end(s, true);
+      bound = bound_next;
+      if (side_done) {
+        HIP_TRY(hipStreamWaitEvent(s->stream, side_done, 0));
+      } else {
+        span_begin(s, true);
+        if (int rc = launch_trace_queue(s, s->w_rays[nxt].as<float4>(), cnt + 4 * g + 1, 1u, bound, hits_next)) return rc;
+        span_end(s, true);
+      }
     }
   }
   // the counters go to pinned host memory behind the kernels; finish_call() turns them into ray counts
