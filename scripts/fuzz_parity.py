@@ -128,7 +128,7 @@ def main():
         s.close()
         # ... and a small frame through the whole pipeline: camera rays, shadow rays (point and spherical lights),
         # reflection / refraction trees, spheres, GI probes over the reference's leaf list where that list exists
-        res = 48
+        res = int(rng.choice([48, 48, 96]))
         view = scenes.look_at_view(tuple(rng.uniform(-1, 1, 3) * 2.5 * ext + np.float64([0, 0, 0.5 * ext])), tuple(rng.uniform(-.2, .2, 3) * ext))
         refl, refr = [(1, 0), (1, 0), (0, 1), (1, 1), (0, 0)][int(rng.integers(0, 5))]
         gi = int(rng.choice([0, 0, 4]))
