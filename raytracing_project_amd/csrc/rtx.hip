@@ -347,7 +347,8 @@ extern "C" int rtx_scene_build(rtx_scene* s) {
   std::vector<uint32_t> regular, wild;     // mesh face ids
   lo.reserve((size_t)ntris * 3); hi.reserve((size_t)ntris * 3);
   float scene_abs = 0.0f;
-  for (size_t i = 0; i < s->verts.size(); ++i) scene_abs = std::max(scene_abs, std::fabs(s->verts[i]));
+  for (size_t i = 0; i < s->verts.size(); ++i)      // (a vertex at infinity makes its own triangles wild, not every box infinite)
+    if (std::isfinite(s->verts[i])) scene_abs = std::max(scene_abs, std::fabs(s->verts[i]));
   const float pad_abs = std::max(2e-5f * scene_abs, 1e-30f);
   const double kWildBelow = [] { const char* e = std::getenv("RTX_WILD_BELOW"); const double v = e ? std::atof(e) : 0.0; return v > 0 ? v : 2.5e-6; }();   // (tuning / test hook)
   auto vert = [&](uint32_t i) { return v3(s->verts[3 * i], s->verts[3 * i + 1], s->verts[3 * i + 2]); };

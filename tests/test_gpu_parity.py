@@ -227,6 +227,20 @@ def test_edge_cases(api, oa):
     assert np.array_equal(face[-len(bad_o):], want["face"])
     assert (face[nb:nb + reps] == face[nb]).all() and face[nb] >= 0
     s2.close()
+    # vertices that are not numbers, infinite or huge: their triangles hit what the reference's arithmetic says
+    # (mostly nothing), the rest of the mesh is unaffected
+    rng = np.random.default_rng(1)
+    ro = rng.uniform(-1.5, 1.5, (20000, 3)).astype(np.float32); rd = rng.normal(size=(20000, 3)).astype(np.float32)
+    for val, where in ((np.nan, [7]), (np.nan, list(range(0, 3000, 37))), (1e38, [5, 6]), (np.inf, [100]), (-np.inf, [11])):
+        vv = sv.copy(); vv[where, 0] = val
+        s3 = api.Scene(vv, si, None, [api.make_material()])
+        s3.set_lights([[0, 3, 0]])
+        s3.commit(0)
+        t3, f3 = s3.trace_closest(ro, rd)
+        h3 = oa.Scene(vv, si, None, [oa.make_mtl()]).closest(ro, rd, threads=16)
+        assert (h3["face"] >= 0).sum() > 500 and np.array_equal(f3, h3["face"]), (val, where[:3])
+        assert_bits_equal(t3, h3["t"], "t with odd vertices")
+        s3.close()
     # invalid options are refused loudly
     with pytest.raises(api.RtxError, match="leaf list"):
         s.render(cam, api.Options(2, 1, 1, 8, 1, 0), (0, 0, 8, 8))
