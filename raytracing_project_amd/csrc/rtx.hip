@@ -347,8 +347,11 @@ extern "C" int rtx_scene_build(rtx_scene* s) {
   std::vector<uint32_t> regular, wild;     // mesh face ids
   lo.reserve((size_t)ntris * 3); hi.reserve((size_t)ntris * 3);
   float scene_abs = 0.0f;
-  for (size_t i = 0; i < s->verts.size(); ++i)      // (a vertex at infinity makes its own triangles wild, not every box infinite)
-    if (std::isfinite(s->verts[i])) scene_abs = std::max(scene_abs, std::fabs(s->verts[i]));
+  // Coordinates beyond kCoordMax (or not numbers) make their own triangles wild instead of stretching the padding of
+  // every box: the slab arithmetic multiplies box coordinates by up to 1e18 (cull_inv) and has to stay finite in fp32.
+  constexpr float kCoordMax = 1e18f;
+  for (size_t i = 0; i < s->verts.size(); ++i)
+    if (std::fabs(s->verts[i]) <= kCoordMax) scene_abs = std::max(scene_abs, std::fabs(s->verts[i]));
   const float pad_abs = std::max(2e-5f * scene_abs, 1e-30f);
   const double kWildBelow = [] { const char* e = std::getenv("RTX_WILD_BELOW"); const double v = e ? std::atof(e) : 0.0; return v > 0 ? v : 2.5e-6; }();   // (tuning / test hook)
   auto vert = [&](uint32_t i) { return v3(s->verts[3 * i], s->verts[3 * i + 1], s->verts[3 * i + 2]); };
@@ -385,7 +388,9 @@ extern "C" int rtx_scene_build(rtx_scene* s) {
     const double duv = du[0] * dv[0] + du[1] * dv[1] + du[2] * dv[2];
     const double dee = de[0] * de[0] + de[1] * de[1] + de[2] * de[2];
     const double q = (duu * dvv > 0) ? (duu * dvv - duv * duv) / (duu * dvv) : 0.0;
-    const bool finite_rec = std::isfinite(D) && std::isfinite(uu) && std::isfinite(vv) && std::isfinite(nq.x + nq.y + nq.z);
+    bool in_range = true;
+    for (const V3& p : {a, b, c}) in_range = in_range && std::fabs(p.x) <= kCoordMax && std::fabs(p.y) <= kCoordMax && std::fabs(p.z) <= kCoordMax;
+    const bool finite_rec = in_range && std::isfinite(D) && std::isfinite(uu) && std::isfinite(vv) && std::isfinite(nq.x + nq.y + nq.z);
     if (!(q >= kWildBelow) || !(dee > 0) || !finite_rec) { wild.push_back(f); continue; }
     const double lu = std::sqrt(duu), lv = std::sqrt(dvv), le = std::sqrt(dee);
     const double longest = std::max(lu, std::max(lv, le));

@@ -65,15 +65,18 @@ def mesh(rng):
     if rng.random() < 0.3:
         Z = T[::53].copy(); Z[:, 2] = Z[:, 1]
         T = np.concatenate([T, Z])                                          # zero-area faces
+    if rng.random() < 0.08:                                                 # a few vertices that are not proper numbers
+        k = rng.integers(0, len(T), int(rng.integers(1, 6)))
+        T[k, rng.integers(0, 3, len(k)), rng.integers(0, 3, len(k))] = rng.choice(np.float32([np.nan, np.inf, -np.inf, 1e38, -3e38]), len(k))
     return T
 
 
 def rays(rng, T, n):
-    ext = float(np.abs(T).max())
+    ext = float(np.abs(T[np.isfinite(T) & (np.abs(T) < 1e30)]).max())
     org = rng.uniform(-1.5, 1.5, (n, 3)) * ext
     d = rng.normal(size=(n, 3))
     k = rng.integers(0, len(T), n)
-    Td = T.astype(np.float64)
+    Td = np.where(np.isfinite(T) & (np.abs(T) < 1e30), T, 0).astype(np.float64)     # (rays are aimed at the ordinary part of the scene)
     bary = rng.dirichlet([1, 1, 1], n)
     target = (Td[k] * bary[:, :, None]).sum(1)
     d[0::2] = (target - org)[0::2]
@@ -87,7 +90,7 @@ def rays(rng, T, n):
     inside = slice(13, n, 32)                       # origins on a surface point, going anywhere
     org[inside] = target[inside]
     org = org.astype(np.float32); d = d.astype(np.float32)
-    o2, d2 = sliver_overshoot_rays(rng, T, n // 4)
+    o2, d2 = sliver_overshoot_rays(rng, Td.astype(np.float32), n // 4)
     return np.concatenate([org, o2]), np.concatenate([d, d2])
 
 
@@ -107,7 +110,7 @@ def main():
         mats = [dict(ka=tuple(rng.uniform(0, .3, 3)), kd=tuple(rng.uniform(.2, .9, 3)), ks=tuple(rng.uniform(0, .8, 3)),
                      ns=float(rng.uniform(2, 40)), d=1.0) for _ in range(nm)]
         tri_mat = rng.integers(0, nm, len(T)).astype(np.int32)
-        ext = float(np.abs(T).max())
+        ext = float(np.abs(T[np.isfinite(T) & (np.abs(T) < 1e30)]).max())
         lights = [list(rng.uniform(-2, 2, 3) * ext) for _ in range(int(rng.integers(1, 3)))]
         s = api.Scene(verts, idx, tri_mat, [api.make_material(**m) for m in mats])
         s.set_lights(lights)
