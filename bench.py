@@ -85,6 +85,43 @@ def spp_offsets(spp):
     return [((a + .5) / n, (b + .5) / n) for b in range(n) for a in range(n)]
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one fresh process per GPU,
+    BEFORE this process has made any GPU call (it never does: it only waits), the way
+    `python -m torch.distributed.run --nproc-per-node N` would.  Rank 0 inherits stdout and prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:          # one rank failed: the others would wait in a collective for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,17 +132,20 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=6144, help="primary rays in the cpu_baseline sample")
     ap.add_argument("--roofline-stride", type=int, default=16, help="every k-th pixel feeds the byte count")
+    ap.add_argument("--no-scaling-proxy", action="store_true")
     args = ap.parse_args()
-
-    import torch
-    from raytracing_project_amd import api, scenes, tiles
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)                      # does not return
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with that many ranks" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import torch
+    from raytracing_project_amd import api, scenes, tiles
+
     # RTX_BENCH_REHEARSE=1: all ranks share GPU 0 and exchange over gloo through host memory -- a dry run
     # of the N > 1 control flow on a one-GPU box (RCCL refuses two ranks on one device).  Its line says
     # so ("rehearsal": true) and is not a measurement.
@@ -306,6 +346,8 @@ def main():
             scene.render_dev(cams[0], opts, rect, f_rgb.data_ptr(), None, f_face.data_ptr())
             result["config"]["rehearsal_equals_full_frame"] = bool(
                 hits == int((f_face >= 0).sum().item()) and torch.equal(img[0].reshape(-1, 3).view(torch.int32), f_rgb.view(torch.int32)))
+    if rank == 0 and world == 1 and not args.no_scaling_proxy:
+        result["scaling_proxy"] = scaling_proxy(scene, cams[0], opts, rect, W, H, torch, dev, tiles, max(5, args.steps))
     if rank == 0 and world == 1 and not args.no_roofline:
         result["roofline"] = roofline(args, wl, scene, info, ms_tot / args.steps, rays_tot / args.steps)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -316,6 +358,36 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     scene.close()
+
+
+def scaling_proxy(scene, cam, opts, rect, W, H, torch, dev, tiles, steps):
+    """Strong scaling rehearsed on one GPU: the share of rank 0 of N (rtx_render_tiles_dev, part 0 of N, the
+    call every rank of an N-GPU run makes) timed alone, two frames in flight like the bench loop.  With perfect
+    scaling part 0 of N costs 1/N of part 0 of 1; the ratio is the render-side bound on the N-GPU speed-up
+    (the RGB gather and reassembly on rank 0 come on top and overlap the next frame's render)."""
+    ms = {}
+    for nparts in (1, 2, 4, 8):
+        kmax = tiles.max_local_tiles(W, H, TILE, nparts)
+        rgb = torch.zeros((kmax * TILE * TILE, 3), dtype=torch.float32, device=dev)
+        face = torch.full((kmax * TILE * TILE, 1), -1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+
+        def run(n):
+            for k in range(n):
+                scene.render_tiles_dev_enqueue(cam, opts, rect, TILE, 0, nparts, rgb.data_ptr(), None, face.data_ptr())
+                if k:
+                    scene.render_finish()
+            scene.render_finish()
+        run(8)                                   # the scheduler tuner starts over when the ray count changes 2x
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize()
+        ms[nparts] = (time.perf_counter() - t0) / steps * 1e3
+    return {"ms_per_frame_part0_of_N": {str(n): ms[n] for n in ms},
+            "render_speedup_bound": {str(n): ms[1] / ms[n] for n in ms},
+            "note": "one GPU renders rank 0's tiles of an N-rank run (same tile size, same round-robin); "
+                    "ms[1] / ms[N] bounds the N-GPU speed-up from the render side"}
 
 
 def oracle_scene(wl):
