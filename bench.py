@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=6144, help="primary rays in the cpu_baseline sample")
     ap.add_argument("--roofline-stride", type=int, default=16, help="every k-th pixel feeds the byte count")
     ap.add_argument("--no-scaling-proxy", action="store_true")
+    ap.add_argument("--inflight", type=int, default=3, choices=[1, 2, 3, 4],
+                    help="frames in flight (rtx_render_*_enqueue): they run side by side on the GPU, each on its own streams")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,7 +184,7 @@ def main():
     # Three sets of output buffers: the render of frame k+1 (librtx's own stream) overlaps the gather
     # and reassembly of frame k (torch's streams); a set is reused only after the torch work that
     # read it has finished (event per set).
-    NSETS = 3
+    NSETS = max(3, args.inflight + 2)
     sets = []
     for _ in range(NSETS):
         b = {"rgb": torch.zeros((npix_local, 3), dtype=torch.float32, device=dev),
@@ -276,14 +278,13 @@ def main():
         out = []
         if not pipelined:
             return [frame() for _ in range(n)]
-        prev = None
+        flying = []
         for _ in range(n):
-            b = frame_enqueue()
-            if prev is not None:
-                out.append(frame_finish(prev))
-            prev = b
-        if prev is not None:
-            out.append(frame_finish(prev))
+            flying.append(frame_enqueue())
+            if len(flying) >= args.inflight:
+                out.append(frame_finish(flying.pop(0)))
+        while flying:
+            out.append(frame_finish(flying.pop(0)))
         return out
 
     def sync():
@@ -314,6 +315,18 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     total_rays = float(agg.sum().item())
     dt = float(tmax.item())
+    # Per-kernel durations for the roofline: frames in flight share the GPU, so the HIP-event spans of the timed
+    # region include time given to the other frames' kernels.  The same frames once more, one at a time
+    # (synchronous calls, nothing beside them): these spans are each kernel's own duration.
+    ms_iso = None
+    if world == 1:
+        ms_iso = np.zeros(3, np.float64)
+        for _ in range(args.steps):
+            for cam in cams:
+                scene.render_dev(cam, opts, rect, sets[0]["rgb"].data_ptr(), None, sets[0]["face"].data_ptr())
+                st = scene.stats()
+                ms_iso += [st.ms_trace_camera, st.ms_trace - st.ms_trace_camera, st.ms_total]
+        ms_iso /= args.steps
     # pixels whose primary ray hit geometry, from the hit ids of the last frame on every rank
     last = sets[(state["k"] - 1) % NSETS]["face"]
     nhit = torch.tensor([float((last >= 0).sum().item())], dtype=torch.float64, device="cpu" if rehearse else dev)
@@ -330,13 +343,14 @@ def main():
             "config": {"workload": args.workload, "triangles": int(info.ntris), "bvh_nodes": int(info.nnodes),
                        "image": [W, H], "lights": len(wl["lights"]), "spp": wl["spp"], "max_bounces": wl["opts"][0],
                        "tile": TILE, "partition": (("image tiles round-robin over %d ranks, scene replicated, RGB gathered to rank 0" % world) if world > 1
-                                     else "one rank renders the whole frame row-major") + ("; two frames in flight (rtx_render_*_enqueue / rtx_render_finish)" if pipelined else ""),
+                                     else "one rank renders the whole frame row-major") + (("; %d frames in flight (rtx_render_*_enqueue / rtx_render_finish)" % args.inflight) if pipelined else ""),
                        "rays_per_frame": {"primary": int(agg[0].item() / args.steps), "shadow": int(agg[1].item() / args.steps),
                                           "reflection": int(agg[2].item() / args.steps)},
                        "pixels_hitting_geometry": hits,
-                       "kernel_ms_per_frame_rank0": {"trace_camera": ms_tot[0] / args.steps,
-                                                      "trace_queue": ms_tot[1] / args.steps,
-                                                      "all_kernels": ms_tot[2] / args.steps}},
+                       # spans of the timed region: with several frames in flight they overlap each other
+                       "kernel_span_ms_per_frame_rank0": {"trace_camera": ms_tot[0] / args.steps,
+                                                           "trace_queue": ms_tot[1] / args.steps,
+                                                           "all_kernels": ms_tot[2] / args.steps}},
         }
     if rank == 0 and rehearse:
         result["config"]["rehearsal"] = True
@@ -347,9 +361,10 @@ def main():
             result["config"]["rehearsal_equals_full_frame"] = bool(
                 hits == int((f_face >= 0).sum().item()) and torch.equal(img[0].reshape(-1, 3).view(torch.int32), f_rgb.view(torch.int32)))
     if rank == 0 and world == 1 and not args.no_scaling_proxy:
-        result["scaling_proxy"] = scaling_proxy(scene, cams[0], opts, rect, W, H, torch, dev, tiles, max(5, args.steps))
+        result["scaling_proxy"] = scaling_proxy(scene, cams[0], opts, rect, W, H, torch, dev, tiles, max(5, args.steps), args.inflight)
     if rank == 0 and world == 1 and not args.no_roofline:
-        result["roofline"] = roofline(args, wl, scene, info, ms_tot / args.steps, rays_tot / args.steps)
+        result["config"]["kernel_ms_per_frame_one_at_a_time"] = {"trace_camera": ms_iso[0], "trace_queue": ms_iso[1], "all_kernels": ms_iso[2]}
+        result["roofline"] = roofline(args, wl, scene, info, ms_iso, rays_tot / args.steps)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, wl)
     if rank == 0:
@@ -360,7 +375,7 @@ def main():
     scene.close()
 
 
-def scaling_proxy(scene, cam, opts, rect, W, H, torch, dev, tiles, steps):
+def scaling_proxy(scene, cam, opts, rect, W, H, torch, dev, tiles, steps, inflight=3):
     """Strong scaling rehearsed on one GPU: the share of rank 0 of N (rtx_render_tiles_dev, part 0 of N, the
     call every rank of an N-GPU run makes) timed alone, two frames in flight like the bench loop.  With perfect
     scaling part 0 of N costs 1/N of part 0 of 1; the ratio is the render-side bound on the N-GPU speed-up
@@ -373,11 +388,15 @@ def scaling_proxy(scene, cam, opts, rect, W, H, torch, dev, tiles, steps):
         torch.cuda.synchronize()
 
         def run(n):
+            flying = 0
             for k in range(n):
                 scene.render_tiles_dev_enqueue(cam, opts, rect, TILE, 0, nparts, rgb.data_ptr(), None, face.data_ptr())
-                if k:
+                flying += 1
+                if flying >= inflight:
                     scene.render_finish()
-            scene.render_finish()
+                    flying -= 1
+            for _ in range(flying):
+                scene.render_finish()
         run(8)                                   # the scheduler tuner starts over when the ray count changes 2x
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -10,7 +10,7 @@
  * followed by a stream synchronise; all others take HOST pointers.
  *
  * Threading: calls on one rtx_scene are serialised by the caller; different scenes are
- * independent (one HIP stream each).  The reference mutates its scene only between
+ * independent (HIP streams of their own).  The reference mutates its scene only between
  * renders (src/main.cpp:63-77); so does this API (mutators need a new rtx_scene_commit).
  *
  * Limits (RTX_ELIMIT beyond them): fewer than 2^28 triangles and 2^26 BVH node groups (~1.4e8 triangles); fewer than 2^31 pixels per call
@@ -209,12 +209,17 @@ int rtx_render(rtx_scene*, const rtx_camera*, const rtx_options*, rtx_rect rect,
 int rtx_render_dev(rtx_scene*, const rtx_camera*, const rtx_options*, rtx_rect rect,
                    float* rgb, float* t, int32_t* face_id);
 /* rtx_render_dev in two halves, for sequences of frames: rtx_render_dev_enqueue queues the call's
- * kernels on the scene's stream and returns; rtx_render_finish waits for the oldest call enqueued
- * and not yet finished and reports its statistics (stats may be NULL; RTX_ESTATE when there is
- * none).  Two calls may be in flight: enqueue frame k+1, then finish frame k, and the GPU never
- * idles between frames.  Calls run in the order they were enqueued (the scene's workspace is
- * shared), the outputs of a call are complete once it is finished, a third enqueue first
- * finishes the oldest call, and any other entry point on the scene finishes all of them.
+ * kernels and returns; rtx_render_finish waits for the oldest call enqueued and not yet handed out and
+ * reports its statistics (stats may be NULL; RTX_ESTATE when there is none).  Up to four calls may be
+ * in flight, each on HIP streams and a workspace of its own: they run SIDE BY SIDE on the GPU (frame
+ * k+1's launches take the CUs that frame k's traversal kernels leave free while their last waves
+ * drain: +29 % rays/s on the 4K soup, +70 % on 1080p frames), so their outputs must not overlap, and
+ * the per-kernel times in their rtx_stats include the time shared with the other calls.  The outputs
+ * of a call are complete once rtx_render_finish has returned for it; a fifth enqueue first finishes
+ * the oldest call (its statistics are then lost), and any synchronous entry point on the scene
+ * finishes all of them.  While the library is still timing its wave schedulers on a scene (its first
+ * seven render calls) enqueued calls run one at a time.  RTX_OVERLAP_FRAMES=0 in the environment
+ * keeps them one at a time always.
  * No counterpart in the reference (raytraceScene returns when the frame is done,
  * src/flyscene.cpp:395-468). */
 int rtx_render_dev_enqueue(rtx_scene*, const rtx_camera*, const rtx_options*, rtx_rect rect,

@@ -63,6 +63,9 @@ struct EventPool {
 
 }  // namespace
 
+// Calls that may be in flight on one scene (rtx_render_*_enqueue): each has its own streams and workspace.
+constexpr int kSlots = 4;
+
 struct rtx_scene {
   // host description
   std::vector<float> verts;
@@ -86,19 +89,29 @@ struct rtx_scene {
   // committed state
   bool committed = false;
   int device = -1;
-  hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;     // bounce launches that overlap the shadow launch of the same generation (run_pipeline)
   BvhBuildResult bvh;
   DevScene dev{};
   DevBuf d_nodes, d_tris, d_tri_face, d_face_nm, d_spheres, d_sph_mat, d_mats, d_lights;
   DevBuf d_slights, d_leafboxes, d_leaf_faces, d_face_pos;
-  // workspace
-  DevBuf w_cam_tab;                  // camera tables (k_camera_tables)
-  DevCamera cam_tab_of{};            // the camera w_cam_tab currently holds the tables of (valid: cam_tab_ok)
-  bool cam_tab_ok = false;
-  DevBuf w_stack_ovf;                // global overflow columns of the per-lane traversal stacks
-  DevBuf w_stack_ovf2;               // ... of the launches on stream2 (they run beside launches on `stream`)
-  DevBuf w_rays[2], w_hits[3], w_parents, w_shadow_rays, w_shadow_hits, w_gi_rays, w_gi_hits, w_counters, w_io[6];
+  // Workspace of one call: its streams and every buffer its kernels write.  Two of them (one per call slot,
+  // below), so that two render calls can be in flight on the GPU at the same time: frame k+1's launches fill the
+  // CUs that frame k's persistent traversal kernels leave free while their last waves drain.
+  struct Slot {
+    hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;     // bounce launches that overlap the shadow launch of the same generation (run_pipeline)
+    DevBuf w_cam_tab;                  // camera tables (k_camera_tables)
+    DevCamera cam_tab_of{};            // the camera w_cam_tab currently holds the tables of (valid: cam_tab_ok)
+    bool cam_tab_ok = false;
+    DevBuf w_stack_ovf;                // global overflow columns of the per-lane traversal stacks
+    DevBuf w_stack_ovf2;               // ... of the launches on stream2 (they run beside launches on `stream`)
+    DevBuf w_rays[2], w_hits[3], w_parents, w_shadow_rays, w_shadow_hits, w_gi_rays, w_gi_hits, w_counters;
+    template <class F> void for_each_buf(F f) {
+      f(w_cam_tab); f(w_stack_ovf); f(w_stack_ovf2); f(w_rays[0]); f(w_rays[1]); f(w_hits[0]); f(w_hits[1]); f(w_hits[2]);
+      f(w_parents); f(w_shadow_rays); f(w_shadow_hits); f(w_gi_rays); f(w_gi_hits); f(w_counters);
+    }
+  };
+  Slot slots[kSlots];
+  DevBuf w_io[6];                      // staging of the host-pointer entry points (synchronous: never in use by a call in flight)
   // Per-call bookkeeping.  Two of them, so that a render call can be enqueued while the one before is
   // still running (rtx_render_dev_enqueue / rtx_render_finish); every other entry point begins and
   // finishes its call in one go.
@@ -112,12 +125,14 @@ struct rtx_scene {
     uint32_t* hc = nullptr;            // pinned host copy of the pipeline's counters
     size_t hc_words = 0;
     bool pending = false;              // enqueued, not finished yet
+    bool throughput = false;           // enqueued, and other calls may run beside it
+    bool unreported = false;           // enqueued by rtx_render_*_enqueue and not yet handed out by rtx_render_finish
     bool pipeline = false, shade = false, shadows = false, tune = false;   // what finish_call has to account for
     int max_gen = 0;
     uint32_t NLS = 0, G = 0;
     rtx_stats stats{};
   };
-  Call calls[2];
+  Call calls[kSlots];
   int cur = 0;
   // Scheduler tuning per launch kind (camera / shadow queue / bounce queue): after a first untimed
   // call, the next calls of a scene run the scheduler modes in turn on the real work, twice each, and
@@ -136,6 +151,8 @@ struct rtx_scene {
 };
 
 static rtx_scene::Call& cur_call(rtx_scene* s) { return s->calls[s->cur]; }
+static rtx_scene::Slot& ws(rtx_scene* s) { return s->slots[s->cur]; }          // the workspace of the current call
+static int finish_call(rtx_scene* s, rtx_scene::Call& c);
 static int trace_grid(const rtx_scene* s) { return s->ncu * 8; }      // 8 blocks x 4 waves = 32 waves per CU
 
 extern "C" const char* rtx_last_error(void) { return g_err.c_str(); }
@@ -165,21 +182,24 @@ extern "C" int rtx_scene_create(const float* verts, uint32_t nverts, const uint3
 static void release_device(rtx_scene* s) {
   if (s->device >= 0) (void)hipSetDevice(s->device);
   DevBuf* bufs[] = {&s->d_nodes, &s->d_tris, &s->d_tri_face, &s->d_face_nm, &s->d_spheres, &s->d_sph_mat, &s->d_mats,
-                    &s->d_lights, &s->d_slights, &s->d_leafboxes, &s->d_leaf_faces, &s->d_face_pos, &s->w_gi_rays,
-                    &s->w_gi_hits, &s->w_stack_ovf, &s->w_cam_tab, &s->w_rays[0], &s->w_rays[1], &s->w_hits[0], &s->w_hits[1], &s->w_hits[2], &s->w_stack_ovf2, &s->w_parents,
-                    &s->w_shadow_rays, &s->w_shadow_hits, &s->w_counters, &s->w_io[0], &s->w_io[1], &s->w_io[2],
-                    &s->w_io[3], &s->w_io[4], &s->w_io[5]};
-  if (s->stream) (void)hipStreamSynchronize(s->stream);      // calls still in flight
-  if (s->stream2) (void)hipStreamSynchronize(s->stream2);
+                    &s->d_lights, &s->d_slights, &s->d_leafboxes, &s->d_leaf_faces, &s->d_face_pos};
+  for (rtx_scene::Slot& w : s->slots) {                        // calls still in flight
+    if (w.stream) (void)hipStreamSynchronize(w.stream);
+    if (w.stream2) (void)hipStreamSynchronize(w.stream2);
+  }
   for (DevBuf* b : bufs) b->release();
-  s->cam_tab_ok = false;
+  for (DevBuf& b : s->w_io) b.release();
+  for (rtx_scene::Slot& w : s->slots) {
+    w.for_each_buf([](DevBuf& b) { b.release(); });
+    w.cam_tab_ok = false;
+    if (w.stream) { (void)hipStreamDestroy(w.stream); w.stream = nullptr; }
+    if (w.stream2) { (void)hipStreamDestroy(w.stream2); w.stream2 = nullptr; }
+  }
   for (rtx_scene::Call& c : s->calls) {
     c.events.release();
     if (c.hc) (void)hipHostFree(c.hc);
-    c.hc = nullptr; c.hc_words = 0; c.pending = false;
+    c.hc = nullptr; c.hc_words = 0; c.pending = false; c.unreported = false;
   }
-  if (s->stream) { (void)hipStreamDestroy(s->stream); s->stream = nullptr; }
-  if (s->stream2) { (void)hipStreamDestroy(s->stream2); s->stream2 = nullptr; }
   s->committed = false;
 }
 
@@ -449,17 +469,25 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail(RTX_EINVAL, "device %d out of range (%d devices)", device, ndev);
+  if (s->device >= 0) {                       // calls still in flight read the buffers this is about to replace
+    (void)hipSetDevice(s->device);
+    for (rtx_scene::Call& c : s->calls) if (int rc = finish_call(s, c)) return rc;
+  }
   if (s->device >= 0 && s->device != device) release_device(s);
   HIP_TRY(hipSetDevice(device));
   s->device = device;
-  if (!s->stream) HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-  if (!s->stream2) HIP_TRY(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
+  // (a process has 4 hardware queues by default and streams take them in turn: the slots' main streams first, so
+  // that calls in flight never share one)
+  for (rtx_scene::Slot& w : s->slots) if (!w.stream) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+  for (rtx_scene::Slot& w : s->slots) if (!w.stream2) HIP_TRY(hipStreamCreateWithFlags(&w.stream2, hipStreamNonBlocking));
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   s->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (int rc = rtx_scene_build(s)) return rc;
-  if (int rc = s->w_stack_ovf.ensure((size_t)trace_grid(s) * kBlock * (kStackDepth - kLdsStack) * 4)) return rc;
-  if (int rc = s->w_stack_ovf2.ensure((size_t)trace_grid(s) * kBlock * (kStackDepth - kLdsStack) * 4)) return rc;
+  for (rtx_scene::Slot& w : s->slots) {
+    if (int rc = w.w_stack_ovf.ensure((size_t)trace_grid(s) * kBlock * (kStackDepth - kLdsStack) * 4)) return rc;
+    if (int rc = w.w_stack_ovf2.ensure((size_t)trace_grid(s) * kBlock * (kStackDepth - kLdsStack) * 4)) return rc;
+  }
   const uint32_t ntris = (uint32_t)s->tri_mat.size();
   const std::vector<float4>& tri_leaf = s->h_tri_leaf;
   const std::vector<int32_t>& tri_face = s->h_tri_face;
@@ -482,7 +510,7 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   // rtx_scene_get_bvh stays the fp32 one {lo, ref, hi, count}.
   std::vector<PackedGroup> dnodes;
   pack_groups(s->bvh.quads, &dnodes);
-  if (int rc = upload(s->d_nodes, dnodes, s->stream)) return rc;
+  if (int rc = upload(s->d_nodes, dnodes, ws(s).stream)) return rc;
   // Device order of the triangle record: {n, D} {v0, vv} {u, uu} {v, uv}, so that the plane
   // stage of the test (most triangles stop there) needs one 16-byte load instead of two; the
   // exported layout of rtx_scene_get_tris stays {v0, D} {u, uu} {v, uv} {n, vv}.
@@ -495,14 +523,14 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
       dtris[k + 2] = u;
       dtris[k + 3] = v;
     }
-    if (int rc = upload(s->d_tris, dtris, s->stream)) return rc;
+    if (int rc = upload(s->d_tris, dtris, ws(s).stream)) return rc;
   }
-  if (int rc = upload(s->d_tri_face, tri_face, s->stream)) return rc;
-  if (int rc = upload(s->d_face_nm, face_nm, s->stream)) return rc;
-  if (int rc = upload(s->d_spheres, ds, s->stream)) return rc;
-  if (int rc = upload(s->d_sph_mat, dsm, s->stream)) return rc;
-  if (int rc = upload(s->d_mats, dm, s->stream)) return rc;
-  if (int rc = upload(s->d_lights, dl, s->stream)) return rc;
+  if (int rc = upload(s->d_tri_face, tri_face, ws(s).stream)) return rc;
+  if (int rc = upload(s->d_face_nm, face_nm, ws(s).stream)) return rc;
+  if (int rc = upload(s->d_spheres, ds, ws(s).stream)) return rc;
+  if (int rc = upload(s->d_sph_mat, dsm, ws(s).stream)) return rc;
+  if (int rc = upload(s->d_mats, dm, ws(s).stream)) return rc;
+  if (int rc = upload(s->d_lights, dl, ws(s).stream)) return rc;
   std::vector<float4> dsl(std::max<size_t>(s->slights.size() / 4, 1));
   for (size_t i = 0; i < s->slights.size() / 4; ++i) dsl[i] = make_float4(s->slights[4 * i], s->slights[4 * i + 1], s->slights[4 * i + 2], s->slights[4 * i + 3]);
   const size_t nleaf = s->have_leaves ? s->leaf_start.size() : 0;
@@ -515,11 +543,11 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   std::vector<int32_t> dlf = s->leaf_faces; if (dlf.empty()) dlf.push_back(0);
   std::vector<int32_t> fpos(std::max<uint32_t>(ntris, 1), 0);
   for (uint32_t k = 0; k < ntris; ++k) fpos[(size_t)tri_face[k]] = (int32_t)k;
-  if (int rc = upload(s->d_slights, dsl, s->stream)) return rc;
-  if (int rc = upload(s->d_leafboxes, dlb, s->stream)) return rc;
-  if (int rc = upload(s->d_leaf_faces, dlf, s->stream)) return rc;
-  if (int rc = upload(s->d_face_pos, fpos, s->stream)) return rc;
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (int rc = upload(s->d_slights, dsl, ws(s).stream)) return rc;
+  if (int rc = upload(s->d_leafboxes, dlb, ws(s).stream)) return rc;
+  if (int rc = upload(s->d_leaf_faces, dlf, ws(s).stream)) return rc;
+  if (int rc = upload(s->d_face_pos, fpos, ws(s).stream)) return rc;
+  HIP_TRY(hipStreamSynchronize(ws(s).stream));
 
   DevScene& d = s->dev;
   d.nodes = s->d_nodes.as<uint4>(); d.tris = s->d_tris.as<float4>(); d.tri_face = s->d_tri_face.as<int>();
@@ -616,13 +644,13 @@ static int grid_for(const rtx_scene* s, size_t items) {
 static void span_begin(rtx_scene* s, bool trace, hipStream_t on = nullptr) {
   rtx_scene::Call& c = cur_call(s);
   hipEvent_t a = c.events.get(), b = c.events.get();
-  (void)hipEventRecord(a, on ? on : s->stream);
+  (void)hipEventRecord(a, on ? on : ws(s).stream);
   (trace ? c.trace_spans : c.all_spans).push_back({a, b});
   if (trace) c.span_kind.push_back(-1);
 }
 static void span_end(rtx_scene* s, bool trace, hipStream_t on = nullptr) {
   rtx_scene::Call& c = cur_call(s);
-  (void)hipEventRecord((trace ? c.trace_spans : c.all_spans).back().second, on ? on : s->stream);
+  (void)hipEventRecord((trace ? c.trace_spans : c.all_spans).back().second, on ? on : ws(s).stream);
 }
 static void tune_update(rtx_scene* s, rtx_scene::Call& c);
 // Waits for an enqueued call, turns its events and counters into rtx_stats, feeds the tuner.
@@ -657,14 +685,20 @@ static int finish_call(rtx_scene* s, rtx_scene::Call& c) {
 }
 // Every call starts here: takes the call slot that is not the most recent one (finishing what it
 // still holds) and opens the span of the whole call.
+static bool overlap_frames(const rtx_scene* s);
 static int stats_begin(rtx_scene* s) {
-  s->cur ^= 1;
+  s->cur = (s->cur + 1) % kSlots;          // the slot used longest ago
   rtx_scene::Call& c = cur_call(s);
   if (int rc = finish_call(s, c)) return rc;
+  c.unreported = false;
+  // The other slot's call may still be running on its own streams: this call then runs beside it.  While the
+  // scheduler tuner is timing launches, calls run one at a time.
+  if (!overlap_frames(s))
+    for (int i = 1; i < kSlots; ++i) if (int rc = finish_call(s, s->calls[(s->cur + i) % kSlots])) return rc;
   c.events.reset(); c.trace_spans.clear(); c.all_spans.clear(); c.camera_span = (size_t)-1;
   c.span_kind.clear();
   for (int k = 0; k < 3; ++k) { c.mode[k] = -1; c.timed[k] = false; }
-  c.pipeline = c.shade = c.shadows = c.tune = false; c.max_gen = 0; c.NLS = c.G = 0;
+  c.pipeline = c.shade = c.shadows = c.tune = c.throughput = false; c.max_gen = 0; c.NLS = c.G = 0;
   std::memset(&c.stats, 0, sizeof c.stats);
   span_begin(s, false);
   return RTX_OK;
@@ -677,8 +711,9 @@ static void stats_enqueue_end(rtx_scene* s) {
 // The synchronous form: every call in flight is finished, oldest first.
 static int stats_end(rtx_scene* s) {
   stats_enqueue_end(s);
-  if (int rc = finish_call(s, s->calls[s->cur ^ 1])) return rc;
-  return finish_call(s, cur_call(s));
+  for (int i = 1; i <= kSlots; ++i) if (int rc = finish_call(s, s->calls[(s->cur + i) % kSlots])) return rc;
+  for (rtx_scene::Call& c : s->calls) c.unreported = false;     // a synchronous call finishes everything
+  return RTX_OK;
 }
 static int check_ready(rtx_scene* s) {
   if (!s) return fail(RTX_EINVAL, "null scene");
@@ -797,24 +832,45 @@ static bool overlap_launches(const rtx_scene* s) {
   if ((s->flags & (RTX_FLAG_SCHED_REFILL | RTX_FLAG_SCHED_GROUPS)) || sched_forced() >= 0) return true;
   return s->tune[KIND_SHADOW].choice >= 0 && s->tune[KIND_BOUNCE].choice >= 0;
 }
+// Two calls in flight run side by side on the two slots' streams (RTX_OVERLAP_FRAMES=0 never, =1 always): by
+// default once every launch kind this scene has used is settled in the tuner, whose trials need the GPU alone.
+static bool overlap_frames(const rtx_scene* s) {
+  static const int forced = [] { const char* e = std::getenv("RTX_OVERLAP_FRAMES"); return e ? std::atoi(e) : -1; }();
+  if (forced == 0) return false;
+  if (forced > 0) return true;
+  if ((s->flags & (RTX_FLAG_SCHED_REFILL | RTX_FLAG_SCHED_GROUPS)) || sched_forced() >= 0) return true;
+  bool any = false;
+  for (const rtx_scene::Tune& T : s->tune) {
+    if (!T.started) continue;
+    any = true;
+    if (T.choice < 0 && !T.too_small) return false;
+  }
+  return any;
+}
+// Grid of a traversal launch over `quads` quads of 64-ray units: what is resident, or one block per quad.
+// (Measured and not kept: smaller grids for enqueued calls, so that a wave draws 4-32 units instead of 2-3 when
+// the launch is small and the other calls in flight take the CUs left free -- no gain on any workload: with
+// fewer waves per SIMD every step waits for its loads instead.)
+static uint32_t trace_blocks(rtx_scene* s, uint64_t quads) {
+  return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(quads, 1), (uint64_t)trace_grid(s));
+}
 static int launch_trace_camera(rtx_scene* s, const DevCamera& C, uint32_t tiles, uint2* hits) {
-  const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(tiles, 1), (uint32_t)trace_grid(s));
+  const uint32_t grid = trace_blocks(s, tiles);
   const uint32_t grid_r = std::min<uint32_t>(grid, (uint32_t)s->ncu * RTX_BLOCKS_REFILL);
   const int mode = sched_pick(s, KIND_CAMERA, (uint64_t)tiles * kBlock);
   if (mode != SCHED_GROUPS)
-    hipLaunchKernelGGL(k_trace_camera<true>, dim3(grid_r), dim3(kBlock), 0, s->stream, s->dev, C, tiles, grab_size(),
-                       mode == SCHED_REFILL_SPLIT ? kTriMinSplit : 1u, s->w_stack_ovf.as<uint32_t>(), hits);
+    hipLaunchKernelGGL(k_trace_camera<true>, dim3(grid_r), dim3(kBlock), 0, ws(s).stream, s->dev, C, tiles, grab_size(),
+                       mode == SCHED_REFILL_SPLIT ? kTriMinSplit : 1u, ws(s).w_stack_ovf.as<uint32_t>(), hits);
   else
-    hipLaunchKernelGGL(k_trace_camera<false>, dim3(grid), dim3(kBlock), 0, s->stream, s->dev, C, tiles, grab_size(), 1u,
-                       s->w_stack_ovf.as<uint32_t>(), hits);
+    hipLaunchKernelGGL(k_trace_camera<false>, dim3(grid), dim3(kBlock), 0, ws(s).stream, s->dev, C, tiles, grab_size(), 1u,
+                       ws(s).w_stack_ovf.as<uint32_t>(), hits);
   return RTX_OK;
 }
 static int launch_trace_queue(rtx_scene* s, const float4* rays, const uint32_t* count, uint32_t stride, uint64_t bound, uint2* hits,
                               bool shadow = false, bool any_blocker = false, bool side = false) {
-  hipStream_t on = side ? s->stream2 : s->stream;                        // side launches have their own overflow columns
-  uint32_t* ovf = (side ? s->w_stack_ovf2 : s->w_stack_ovf).as<uint32_t>();
-  const uint64_t blocks = (bound * stride + kBlock - 1) / kBlock;
-  const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, (uint64_t)trace_grid(s)));
+  hipStream_t on = side ? ws(s).stream2 : ws(s).stream;                        // side launches have their own overflow columns
+  uint32_t* ovf = (side ? ws(s).w_stack_ovf2 : ws(s).w_stack_ovf).as<uint32_t>();
+  const uint32_t grid = trace_blocks(s, (bound * stride + kBlock - 1) / kBlock);
   const uint32_t grid_r = std::min<uint32_t>(grid, (uint32_t)s->ncu * RTX_BLOCKS_REFILL);
   const int mode = sched_pick(s, shadow ? KIND_SHADOW : KIND_BOUNCE, bound * stride);
   const uint32_t bounded = shadow ? (any_blocker ? 3u : 1u) : 0u;
@@ -829,13 +885,13 @@ static int launch_trace_queue(rtx_scene* s, const float4* rays, const uint32_t* 
 
 // Traces `n` caller rays held on the device (xyz arrays) into w_hits[0]; w_rays[0] keeps the records.
 static int trace_rays_dev(rtx_scene* s, const float* d_o, const float* d_d, uint32_t n) {
-  if (int rc = s->w_rays[0].ensure((size_t)n * 32)) return rc;
-  if (int rc = s->w_hits[0].ensure((size_t)n * 8)) return rc;
-  if (int rc = s->w_counters.ensure(64)) return rc;
-  HIP_TRY(hipMemcpyAsync(s->w_counters.p, &n, 4, hipMemcpyHostToDevice, s->stream));
-  hipLaunchKernelGGL(k_make_rays, dim3((n + 255) / 256), dim3(256), 0, s->stream, d_o, d_d, n, s->w_rays[0].as<float4>());
+  if (int rc = ws(s).w_rays[0].ensure((size_t)n * 32)) return rc;
+  if (int rc = ws(s).w_hits[0].ensure((size_t)n * 8)) return rc;
+  if (int rc = ws(s).w_counters.ensure(64)) return rc;
+  HIP_TRY(hipMemcpyAsync(ws(s).w_counters.p, &n, 4, hipMemcpyHostToDevice, ws(s).stream));
+  hipLaunchKernelGGL(k_make_rays, dim3((n + 255) / 256), dim3(256), 0, ws(s).stream, d_o, d_d, n, ws(s).w_rays[0].as<float4>());
   span_begin(s, true);
-  if (int rc = launch_trace_queue(s, s->w_rays[0].as<float4>(), s->w_counters.as<uint32_t>(), 1u, n, s->w_hits[0].as<uint2>())) return rc;
+  if (int rc = launch_trace_queue(s, ws(s).w_rays[0].as<float4>(), ws(s).w_counters.as<uint32_t>(), 1u, n, ws(s).w_hits[0].as<uint2>())) return rc;
   span_end(s, true);
   return RTX_OK;
 }
@@ -844,10 +900,11 @@ extern "C" int rtx_trace_closest_dev(rtx_scene* s, const float* o, const float* 
   if (int rc = check_ready(s)) return rc;
   if (n == 0) return RTX_OK;
   if (!o || !d) return fail(RTX_EINVAL, "null ray arrays");
+  if (n >= (1u << 31)) return fail(RTX_ELIMIT, "too many rays");
   if (int rc = stats_begin(s)) return rc;
   if (int rc = trace_rays_dev(s, o, d, n)) return rc;
-  hipLaunchKernelGGL(k_unpack_hits, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->dev, s->w_rays[0].as<float4>(),
-                     s->w_hits[0].as<uint2>(), n, t, face, (float*)nullptr, (float*)nullptr, (int*)nullptr);
+  hipLaunchKernelGGL(k_unpack_hits, dim3((n + 255) / 256), dim3(256), 0, ws(s).stream, s->dev, ws(s).w_rays[0].as<float4>(),
+                     ws(s).w_hits[0].as<uint2>(), n, t, face, (float*)nullptr, (float*)nullptr, (int*)nullptr);
   cur_call(s).stats.rays_primary = n;
   return stats_end(s);
 }
@@ -857,6 +914,8 @@ extern "C" int rtx_trace_closest(rtx_scene* s, const float* o, const float* d, u
   if (int rc = check_ready(s)) return rc;
   if (n == 0) return RTX_OK;
   if (!o || !d) return fail(RTX_EINVAL, "null ray arrays");
+  if (n >= (1u << 31)) return fail(RTX_ELIMIT, "too many rays");
+  if (int rc = stats_begin(s)) return rc;      // (takes the call slot: its stream and workspace from here on)
   const size_t b3 = (size_t)n * 12, b1 = (size_t)n * 4;
   if (int rc = s->w_io[0].ensure(b3)) return rc;
   if (int rc = s->w_io[1].ensure(b3)) return rc;
@@ -864,14 +923,13 @@ extern "C" int rtx_trace_closest(rtx_scene* s, const float* o, const float* d, u
   if (int rc = s->w_io[3].ensure(b1)) return rc;
   if (int rc = s->w_io[4].ensure(b3 * 2)) return rc;
   if (int rc = s->w_io[5].ensure(b1)) return rc;
-  HIP_TRY(hipMemcpyAsync(s->w_io[0].p, o, b3, hipMemcpyHostToDevice, s->stream));
-  HIP_TRY(hipMemcpyAsync(s->w_io[1].p, d, b3, hipMemcpyHostToDevice, s->stream));
-  if (int rc = stats_begin(s)) return rc;
+  HIP_TRY(hipMemcpyAsync(s->w_io[0].p, o, b3, hipMemcpyHostToDevice, ws(s).stream));
+  HIP_TRY(hipMemcpyAsync(s->w_io[1].p, d, b3, hipMemcpyHostToDevice, ws(s).stream));
   if (int rc = trace_rays_dev(s, s->w_io[0].as<float>(), s->w_io[1].as<float>(), n)) return rc;
   float* d_n = s->w_io[4].as<float>();
   float* d_p = d_n + (size_t)n * 3;
-  hipLaunchKernelGGL(k_unpack_hits, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->dev, s->w_rays[0].as<float4>(),
-                     s->w_hits[0].as<uint2>(), n, s->w_io[2].as<float>(), s->w_io[3].as<int>(), d_n, d_p, s->w_io[5].as<int>());
+  hipLaunchKernelGGL(k_unpack_hits, dim3((n + 255) / 256), dim3(256), 0, ws(s).stream, s->dev, ws(s).w_rays[0].as<float4>(),
+                     ws(s).w_hits[0].as<uint2>(), n, s->w_io[2].as<float>(), s->w_io[3].as<int>(), d_n, d_p, s->w_io[5].as<int>());
   cur_call(s).stats.rays_primary = n;
   if (int rc = stats_end(s)) return rc;
   if (t) HIP_TRY(hipMemcpy(t, s->w_io[2].p, b1, hipMemcpyDeviceToHost));
@@ -887,25 +945,26 @@ extern "C" int rtx_trace_visible(rtx_scene* s, const float* light, const float* 
   if (int rc = check_ready(s)) return rc;
   if (n == 0) return RTX_OK;
   if (!light || !pos || !visible) return fail(RTX_EINVAL, "null argument");
+  if (n >= (1u << 31)) return fail(RTX_ELIMIT, "too many rays");
+  if (int rc = stats_begin(s)) return rc;
   const size_t b3 = (size_t)n * 12;
   if (int rc = s->w_io[0].ensure(b3)) return rc;
   if (int rc = s->w_io[1].ensure(b3)) return rc;
   if (int rc = s->w_io[2].ensure(n)) return rc;
   if (int rc = s->w_io[3].ensure((size_t)n * 4)) return rc;
-  if (int rc = s->w_rays[0].ensure((size_t)n * 32)) return rc;
-  if (int rc = s->w_hits[0].ensure((size_t)n * 8)) return rc;
-  if (int rc = s->w_counters.ensure(64)) return rc;
-  HIP_TRY(hipMemcpyAsync(s->w_io[0].p, light, b3, hipMemcpyHostToDevice, s->stream));
-  HIP_TRY(hipMemcpyAsync(s->w_io[1].p, pos, b3, hipMemcpyHostToDevice, s->stream));
-  HIP_TRY(hipMemcpyAsync(s->w_counters.p, &n, 4, hipMemcpyHostToDevice, s->stream));
-  if (int rc = stats_begin(s)) return rc;
-  hipLaunchKernelGGL(k_make_shadow_rays, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->w_io[0].as<float>(),
-                     s->w_io[1].as<float>(), n, s->w_rays[0].as<float4>());
+  if (int rc = ws(s).w_rays[0].ensure((size_t)n * 32)) return rc;
+  if (int rc = ws(s).w_hits[0].ensure((size_t)n * 8)) return rc;
+  if (int rc = ws(s).w_counters.ensure(64)) return rc;
+  HIP_TRY(hipMemcpyAsync(s->w_io[0].p, light, b3, hipMemcpyHostToDevice, ws(s).stream));
+  HIP_TRY(hipMemcpyAsync(s->w_io[1].p, pos, b3, hipMemcpyHostToDevice, ws(s).stream));
+  HIP_TRY(hipMemcpyAsync(ws(s).w_counters.p, &n, 4, hipMemcpyHostToDevice, ws(s).stream));
+  hipLaunchKernelGGL(k_make_shadow_rays, dim3((n + 255) / 256), dim3(256), 0, ws(s).stream, s->w_io[0].as<float>(),
+                     s->w_io[1].as<float>(), n, ws(s).w_rays[0].as<float4>());
   span_begin(s, true);
-  if (int rc = launch_trace_queue(s, s->w_rays[0].as<float4>(), s->w_counters.as<uint32_t>(), 1u, n, s->w_hits[0].as<uint2>(), true)) return rc;
+  if (int rc = launch_trace_queue(s, ws(s).w_rays[0].as<float4>(), ws(s).w_counters.as<uint32_t>(), 1u, n, ws(s).w_hits[0].as<uint2>(), true)) return rc;
   span_end(s, true);
-  hipLaunchKernelGGL(k_visible, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->dev, s->w_io[0].as<float>(),
-                     s->w_rays[0].as<float4>(), s->w_hits[0].as<uint2>(), n, s->w_io[2].as<unsigned char>(), s->w_io[3].as<int>());
+  hipLaunchKernelGGL(k_visible, dim3((n + 255) / 256), dim3(256), 0, ws(s).stream, s->dev, s->w_io[0].as<float>(),
+                     ws(s).w_rays[0].as<float4>(), ws(s).w_hits[0].as<uint2>(), n, s->w_io[2].as<unsigned char>(), s->w_io[3].as<int>());
   cur_call(s).stats.rays_shadow = n;
   if (int rc = stats_end(s)) return rc;
   HIP_TRY(hipMemcpy(visible, s->w_io[2].p, n, hipMemcpyDeviceToHost));
@@ -983,12 +1042,17 @@ extern "C" int rtx_render_finish(rtx_scene* s, rtx_stats* out) {
   if (!s) return fail(RTX_EINVAL, "null scene");
   if (s->device < 0) return fail(RTX_ESTATE, "no enqueued render call to finish");
   HIP_TRY(hipSetDevice(s->device));          // (a scene changed after the enqueue can still finish what it started)
-  rtx_scene::Call& older = s->calls[s->cur ^ 1];
-  rtx_scene::Call& c = older.pending ? older : cur_call(s);
-  if (!c.pending) return fail(RTX_ESTATE, "no enqueued render call to finish");
-  if (int rc = finish_call(s, c)) return rc;
-  if (out) *out = c.stats;
-  return RTX_OK;
+  // the oldest enqueued call not handed out yet (the library may have waited for it already: calls run one at a
+  // time while the scheduler tuner is timing them)
+  for (int i = 1; i <= kSlots; ++i) {
+    rtx_scene::Call& c = s->calls[(s->cur + i) % kSlots];
+    if (!c.unreported) continue;
+    if (int rc = finish_call(s, c)) return rc;
+    c.unreported = false;
+    if (out) *out = c.stats;
+    return RTX_OK;
+  }
+  return fail(RTX_ESTATE, "no enqueued render call to finish");
 }
 
 extern "C" int rtx_tiles_count(rtx_rect rect, int32_t tile_size, int32_t part, int32_t nparts) {
@@ -1040,6 +1104,7 @@ static int render_tiles_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opti
     if (wait) return RTX_OK;
     if (int rc = stats_begin(s)) return rc;
     stats_enqueue_end(s);
+    cur_call(s).unreported = true;
     return RTX_OK;
   }
   if ((int64_t)nt * tile_size * tile_size >= (1ll << 31)) return fail(RTX_ELIMIT, "too many pixels in this part");
@@ -1073,44 +1138,45 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
   const uint64_t max_nodes = tree ? ((uint64_t)pr.n0 << max_gen) : pr.n0;
   // ray indices are 32-bit in the kernels and a wave's next unit may lie up to one grid of units past the end
   if (max_nodes * std::max<uint64_t>(std::max(NLS, G), 1) >= (1ull << 31)) return fail(RTX_ELIMIT, "ray queue would exceed 2^31 entries");
-  if (int rc = s->w_hits[0].ensure((size_t)pr.n0 * 8)) return rc;
+  if (int rc = ws(s).w_hits[0].ensure((size_t)pr.n0 * 8)) return rc;
   if (shade) {
-    if (int rc = s->w_parents.ensure((size_t)max_nodes * 4)) return rc;
+    if (int rc = ws(s).w_parents.ensure((size_t)max_nodes * 4)) return rc;
     if (opt->shadows) {
-      if (int rc = s->w_shadow_rays.ensure((size_t)max_nodes * NLS * 32)) return rc;
-      if (int rc = s->w_shadow_hits.ensure((size_t)max_nodes * NLS * 8)) return rc;
+      if (int rc = ws(s).w_shadow_rays.ensure((size_t)max_nodes * NLS * 32)) return rc;
+      if (int rc = ws(s).w_shadow_hits.ensure((size_t)max_nodes * NLS * 8)) return rc;
     }
     if (G) {
-      if (int rc = s->w_gi_rays.ensure((size_t)max_nodes * G * 32)) return rc;
-      if (int rc = s->w_gi_hits.ensure((size_t)max_nodes * G * 8)) return rc;
+      if (int rc = ws(s).w_gi_rays.ensure((size_t)max_nodes * G * 32)) return rc;
+      if (int rc = ws(s).w_gi_hits.ensure((size_t)max_nodes * G * 8)) return rc;
     }
     if (max_gen > 0) {
-      if (int rc = s->w_rays[0].ensure((size_t)max_nodes * 32)) return rc;
-      if (int rc = s->w_rays[1].ensure((size_t)max_nodes * 32)) return rc;
-      if (int rc = s->w_hits[1].ensure((size_t)max_nodes * 8)) return rc;
-      if (max_gen > 1) { if (int rc = s->w_hits[2].ensure((size_t)max_nodes * 8)) return rc; }
+      if (int rc = ws(s).w_rays[0].ensure((size_t)max_nodes * 32)) return rc;
+      if (int rc = ws(s).w_rays[1].ensure((size_t)max_nodes * 32)) return rc;
+      if (int rc = ws(s).w_hits[1].ensure((size_t)max_nodes * 8)) return rc;
+      if (max_gen > 1) { if (int rc = ws(s).w_hits[2].ensure((size_t)max_nodes * 8)) return rc; }
     }
   }
   // counters: per generation g, [4g] = #parents, [4g+1] = #nodes of generation g+1, [4g+2] = #refraction rays spawned
-  if (int rc = s->w_counters.ensure((size_t)(max_gen + 2) * 16 + 16)) return rc;
-  HIP_TRY(hipMemsetAsync(s->w_counters.p, 0, (size_t)(max_gen + 2) * 16, s->stream));
-  uint32_t* cnt = s->w_counters.as<uint32_t>();
+  if (int rc = ws(s).w_counters.ensure((size_t)(max_gen + 2) * 16 + 16)) return rc;
+  HIP_TRY(hipMemsetAsync(ws(s).w_counters.p, 0, (size_t)(max_gen + 2) * 16, ws(s).stream));
+  uint32_t* cnt = ws(s).w_counters.as<uint32_t>();
   uint32_t* n0_dev = cnt + (size_t)(max_gen + 2) * 4;       // device copy of n0 for the queue kernel of caller rays
-  if (!pr.camera) HIP_TRY(hipMemcpyAsync(n0_dev, &pr.n0, 4, hipMemcpyHostToDevice, s->stream));
+  if (!pr.camera) HIP_TRY(hipMemcpyAsync(n0_dev, &pr.n0, 4, hipMemcpyHostToDevice, ws(s).stream));
 
   span_begin(s, true);
   if (pr.camera) {
     cur_call(s).camera_span = cur_call(s).trace_spans.size() - 1;
-    if (int rc = launch_trace_camera(s, pr.C, pr.tiles, s->w_hits[0].as<uint2>())) return rc;
+    if (int rc = launch_trace_camera(s, pr.C, pr.tiles, ws(s).w_hits[0].as<uint2>())) return rc;
   } else {
-    if (int rc = launch_trace_queue(s, s->w_rays[0].as<float4>(), n0_dev, 1u, pr.n0, s->w_hits[0].as<uint2>())) return rc;
+    if (int rc = launch_trace_queue(s, ws(s).w_rays[0].as<float4>(), n0_dev, 1u, pr.n0, ws(s).w_hits[0].as<uint2>())) return rc;
   }
   span_end(s, true);
 
   const float th_gi = G ? (float)(M_PI * 2 / (double)G) : 0.0f;      // Ray::resendRay: float theta = M_PI * 2 / n
   const float th_sl = (float)(M_PI * 2 / 4);                          // Shader::getNPointsOnCircle with n = 4
   uint64_t bound = pr.n0;                                             // host-side upper bound of the node count
-  const bool overlap = max_gen > 0 && shade && overlap_launches(s);
+  // (not for calls that run beside other calls: the GPU is full then, and the extra stream only costs -- hall -2.5 %)
+  const bool overlap = max_gen > 0 && shade && !cur_call(s).throughput && overlap_launches(s);
   for (int g = 0; g <= max_gen; ++g) {
     const int cur = g & 1, nxt = cur ^ 1;
     PipeArgs A;
@@ -1119,19 +1185,19 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
     A.shadows = opt->shadows; A.skip_zero_weight = opt->skip_zero_weight; A.atomic_accum = tree ? 1 : 0;
     A.n0 = pr.n0;
     A.nrays = g == 0 ? nullptr : cnt + 4 * (g - 1) + 1;
-    A.rays = (pr.camera && g == 0) ? nullptr : s->w_rays[cur].as<float4>();
+    A.rays = (pr.camera && g == 0) ? nullptr : ws(s).w_rays[cur].as<float4>();
     // hits of generation g: [0] for the first, then [1] and [2] in turn (the trace of generation g+1 may run while
     // k_resolve still reads those of g)
-    A.hits = s->w_hits[g == 0 ? 0 : 1 + ((g - 1) & 1)].as<uint2>();
-    uint2* hits_next = s->w_hits[1 + (g & 1)].as<uint2>();
+    A.hits = ws(s).w_hits[g == 0 ? 0 : 1 + ((g - 1) & 1)].as<uint2>();
+    uint2* hits_next = ws(s).w_hits[1 + (g & 1)].as<uint2>();
     A.rgb = rgb; A.out_t = t; A.out_face = face;
-    A.parents = s->w_parents.as<uint32_t>();
-    A.shadow_rays = s->w_shadow_rays.as<float4>(); A.shadow_hits = s->w_shadow_hits.as<uint2>();
-    A.gi_q = s->w_gi_rays.as<float4>(); A.gi_hits = s->w_gi_hits.as<uint2>();
-    A.next_rays = s->w_rays[nxt].as<float4>();
+    A.parents = ws(s).w_parents.as<uint32_t>();
+    A.shadow_rays = ws(s).w_shadow_rays.as<float4>(); A.shadow_hits = ws(s).w_shadow_hits.as<uint2>();
+    A.gi_q = ws(s).w_gi_rays.as<float4>(); A.gi_hits = ws(s).w_gi_hits.as<uint2>();
+    A.next_rays = ws(s).w_rays[nxt].as<float4>();
     A.counters = cnt + 4 * g;
     A.gi_sin = sinf(th_gi); A.gi_cos = cosf(th_gi); A.sl_sin = sinf(th_sl); A.sl_cos = cosf(th_sl);
-    hipLaunchKernelGGL(k_shade, dim3(grid_for(s, bound)), dim3(kBlock), 0, s->stream, A);
+    hipLaunchKernelGGL(k_shade, dim3(grid_for(s, bound)), dim3(kBlock), 0, ws(s).stream, A);
     if (!shade) break;
     // The bounce rays of generation g+1 and the shadow rays of g both come out of k_shade and do not depend on
     // each other: with overlap on, the bounce launch goes to stream2 and fills the CUs that the shadow launch
@@ -1143,32 +1209,32 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
       rtx_scene::Call& cc = cur_call(s);
       hipEvent_t shaded = cc.events.get();
       side_done = cc.events.get();
-      HIP_TRY(hipEventRecord(shaded, s->stream));
-      HIP_TRY(hipStreamWaitEvent(s->stream2, shaded, 0));
-      span_begin(s, true, s->stream2);
-      if (int rc = launch_trace_queue(s, s->w_rays[nxt].as<float4>(), cnt + 4 * g + 1, 1u, bound_next, hits_next, false, false, true)) return rc;
-      span_end(s, true, s->stream2);
-      HIP_TRY(hipEventRecord(side_done, s->stream2));
+      HIP_TRY(hipEventRecord(shaded, ws(s).stream));
+      HIP_TRY(hipStreamWaitEvent(ws(s).stream2, shaded, 0));
+      span_begin(s, true, ws(s).stream2);
+      if (int rc = launch_trace_queue(s, ws(s).w_rays[nxt].as<float4>(), cnt + 4 * g + 1, 1u, bound_next, hits_next, false, false, true)) return rc;
+      span_end(s, true, ws(s).stream2);
+      HIP_TRY(hipEventRecord(side_done, ws(s).stream2));
     }
     if (opt->shadows && NLS) {
       span_begin(s, true);
-      if (int rc = launch_trace_queue(s, s->w_shadow_rays.as<float4>(), cnt + 4 * g, NLS, bound, s->w_shadow_hits.as<uint2>(), true, true)) return rc;
+      if (int rc = launch_trace_queue(s, ws(s).w_shadow_rays.as<float4>(), cnt + 4 * g, NLS, bound, ws(s).w_shadow_hits.as<uint2>(), true, true)) return rc;
       span_end(s, true);
     }
     if (G) {
       span_begin(s, true);
-      hipLaunchKernelGGL(k_trace_gi, dim3(grid_for(s, bound * G)), dim3(kBlock), 0, s->stream, s->dev, s->w_gi_rays.as<float4>(),
-                         cnt + 4 * g, G, s->w_gi_hits.as<uint2>());
+      hipLaunchKernelGGL(k_trace_gi, dim3(grid_for(s, bound * G)), dim3(kBlock), 0, ws(s).stream, s->dev, ws(s).w_gi_rays.as<float4>(),
+                         cnt + 4 * g, G, ws(s).w_gi_hits.as<uint2>());
       span_end(s, true);
     }
-    hipLaunchKernelGGL(k_resolve, dim3(grid_for(s, bound)), dim3(kBlock), 0, s->stream, A);
+    hipLaunchKernelGGL(k_resolve, dim3(grid_for(s, bound)), dim3(kBlock), 0, ws(s).stream, A);
     if (g < max_gen) {
       bound = bound_next;
       if (side_done) {
-        HIP_TRY(hipStreamWaitEvent(s->stream, side_done, 0));
+        HIP_TRY(hipStreamWaitEvent(ws(s).stream, side_done, 0));
       } else {
         span_begin(s, true);
-        if (int rc = launch_trace_queue(s, s->w_rays[nxt].as<float4>(), cnt + 4 * g + 1, 1u, bound, hits_next)) return rc;
+        if (int rc = launch_trace_queue(s, ws(s).w_rays[nxt].as<float4>(), cnt + 4 * g + 1, 1u, bound, hits_next)) return rc;
         span_end(s, true);
       }
     }
@@ -1182,7 +1248,7 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
     HIP_TRY(hipHostMalloc((void**)&c.hc, (words + 64) * 4, hipHostMallocDefault));
     c.hc_words = words + 64;
   }
-  HIP_TRY(hipMemcpyAsync(c.hc, s->w_counters.p, words * 4, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(c.hc, ws(s).w_counters.p, words * 4, hipMemcpyDeviceToHost, ws(s).stream));
   c.pipeline = true; c.shade = shade; c.shadows = opt->shadows != 0; c.max_gen = max_gen; c.NLS = NLS; c.G = G;
   return RTX_OK;
 }
@@ -1190,15 +1256,16 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
 static int render_impl(rtx_scene* s, const DevCamera& C, uint32_t npix, uint32_t tiles, const rtx_options* opt,
                        float* rgb, float* t, int32_t* face, bool wait) {
   if (int rc = stats_begin(s)) return rc;
-  const size_t tab_cap = s->w_cam_tab.cap;
-  if (int rc = s->w_cam_tab.ensure((size_t)(C.w + C.h) * 4)) return rc;
-  if (s->w_cam_tab.cap != tab_cap) s->cam_tab_ok = false;      // a new allocation (maybe at the old address)
+  cur_call(s).throughput = !wait && overlap_frames(s);
+  const size_t tab_cap = ws(s).w_cam_tab.cap;
+  if (int rc = ws(s).w_cam_tab.ensure((size_t)(C.w + C.h) * 4)) return rc;
+  if (ws(s).w_cam_tab.cap != tab_cap) ws(s).cam_tab_ok = false;      // a new allocation (maybe at the old address)
   Primary pr; pr.camera = true; pr.C = C; pr.n0 = npix; pr.tiles = tiles; pr.bounce0 = 0;
-  pr.C.tab = s->w_cam_tab.as<float>();
+  pr.C.tab = ws(s).w_cam_tab.as<float>();
   // the tables depend on the camera and the rectangle only: frames of one camera reuse them
-  if (!s->cam_tab_ok || std::memcmp(&s->cam_tab_of, &pr.C, sizeof(DevCamera)) != 0) {
-    hipLaunchKernelGGL(k_camera_tables, dim3((uint32_t)(C.w + C.h + 255) / 256), dim3(256), 0, s->stream, pr.C, s->w_cam_tab.as<float>());
-    s->cam_tab_of = pr.C; s->cam_tab_ok = true;
+  if (!ws(s).cam_tab_ok || std::memcmp(&ws(s).cam_tab_of, &pr.C, sizeof(DevCamera)) != 0) {
+    hipLaunchKernelGGL(k_camera_tables, dim3((uint32_t)(C.w + C.h + 255) / 256), dim3(256), 0, ws(s).stream, pr.C, ws(s).w_cam_tab.as<float>());
+    ws(s).cam_tab_of = pr.C; ws(s).cam_tab_ok = true;
   }
   if (int rc = run_pipeline(s, pr, opt, rgb, t, face)) return rc;
   uint64_t live = npix;
@@ -1216,6 +1283,7 @@ static int render_impl(rtx_scene* s, const DevCamera& C, uint32_t npix, uint32_t
   cur_call(s).tune = true;
   if (wait) return stats_end(s);
   stats_enqueue_end(s);
+  cur_call(s).unreported = true;
   return RTX_OK;
 }
 
@@ -1230,18 +1298,21 @@ extern "C" int rtx_trace_shade(rtx_scene* s, const rtx_options* opt, const float
   rtx_camera dummy{};
   if (int rc = check_render_args(s, &dummy, opt, rgb)) return rc;
   const size_t b3 = (size_t)n * 12;
-  if (int rc = s->w_io[0].ensure(b3)) return rc;
-  if (int rc = s->w_io[1].ensure(b3)) return rc;
-  if (int rc = s->w_io[2].ensure(b3)) return rc;
   const bool tree = opt->reflection && opt->refraction;
   const int max_gen = std::max(0, opt->max_bounces - bounce);
   const uint64_t max_nodes = tree ? ((uint64_t)n << max_gen) : n;
-  if (int rc = s->w_rays[0].ensure((size_t)max_nodes * 32)) return rc;
-  HIP_TRY(hipMemcpyAsync(s->w_io[0].p, o, b3, hipMemcpyHostToDevice, s->stream));
-  HIP_TRY(hipMemcpyAsync(s->w_io[1].p, d, b3, hipMemcpyHostToDevice, s->stream));
+  // the limit first, so that an oversize request is RTX_ELIMIT rather than a failed allocation
+  const uint64_t per_node = std::max<uint64_t>(std::max<uint64_t>(s->dev.nlights + 5u * s->dev.nsl, (uint64_t)std::max(opt->gi_rays, 0)), 1);
+  if (max_nodes * per_node >= (1ull << 31)) return fail(RTX_ELIMIT, "ray queue would exceed 2^31 entries");
   if (int rc = stats_begin(s)) return rc;
-  hipLaunchKernelGGL(k_make_nodes, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->w_io[0].as<float>(), s->w_io[1].as<float>(), n,
-                     inside ? 1 : 0, s->w_rays[0].as<float4>());
+  if (int rc = s->w_io[0].ensure(b3)) return rc;
+  if (int rc = s->w_io[1].ensure(b3)) return rc;
+  if (int rc = s->w_io[2].ensure(b3)) return rc;
+  if (int rc = ws(s).w_rays[0].ensure((size_t)max_nodes * 32)) return rc;
+  HIP_TRY(hipMemcpyAsync(s->w_io[0].p, o, b3, hipMemcpyHostToDevice, ws(s).stream));
+  HIP_TRY(hipMemcpyAsync(s->w_io[1].p, d, b3, hipMemcpyHostToDevice, ws(s).stream));
+  hipLaunchKernelGGL(k_make_nodes, dim3((n + 255) / 256), dim3(256), 0, ws(s).stream, s->w_io[0].as<float>(), s->w_io[1].as<float>(), n,
+                     inside ? 1 : 0, ws(s).w_rays[0].as<float4>());
   Primary pr; pr.camera = false; std::memset(&pr.C, 0, sizeof pr.C); pr.n0 = n; pr.tiles = 0; pr.bounce0 = bounce;
   if (int rc = run_pipeline(s, pr, opt, s->w_io[2].as<float>(), nullptr, nullptr)) return rc;
   cur_call(s).stats.rays_primary = n;
@@ -1261,9 +1332,9 @@ extern "C" int rtx_camera_points(rtx_scene* s, const rtx_camera* cam, const floa
   if (n == 0) return RTX_OK;
   if (int rc = s->w_io[0].ensure((size_t)n * 8)) return rc;
   if (int rc = s->w_io[1].ensure((size_t)n * 12)) return rc;
-  HIP_TRY(hipMemcpyAsync(s->w_io[0].p, ij, (size_t)n * 8, hipMemcpyHostToDevice, s->stream));
-  hipLaunchKernelGGL(k_camera_points, dim3((n + 255) / 256), dim3(256), 0, s->stream, C, s->w_io[0].as<float>(), n, s->w_io[1].as<float>());
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpyAsync(s->w_io[0].p, ij, (size_t)n * 8, hipMemcpyHostToDevice, ws(s).stream));
+  hipLaunchKernelGGL(k_camera_points, dim3((n + 255) / 256), dim3(256), 0, ws(s).stream, C, s->w_io[0].as<float>(), n, s->w_io[1].as<float>());
+  HIP_TRY(hipStreamSynchronize(ws(s).stream));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(world, s->w_io[1].p, (size_t)n * 12, hipMemcpyDeviceToHost));
   return RTX_OK;
@@ -1280,11 +1351,11 @@ extern "C" int rtx_intersect_box(rtx_scene* s, const float* bmin, const float* b
   if (int rc = s->w_io[0].ensure(b3)) return rc;
   if (int rc = s->w_io[1].ensure(b3)) return rc;
   if (int rc = s->w_io[2].ensure((size_t)n * 4)) return rc;
-  HIP_TRY(hipMemcpyAsync(s->w_io[0].p, o, b3, hipMemcpyHostToDevice, s->stream));
-  HIP_TRY(hipMemcpyAsync(s->w_io[1].p, d, b3, hipMemcpyHostToDevice, s->stream));
-  hipLaunchKernelGGL(k_ref_box, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->w_io[0].as<float>(), s->w_io[1].as<float>(), n,
+  HIP_TRY(hipMemcpyAsync(s->w_io[0].p, o, b3, hipMemcpyHostToDevice, ws(s).stream));
+  HIP_TRY(hipMemcpyAsync(s->w_io[1].p, d, b3, hipMemcpyHostToDevice, ws(s).stream));
+  hipLaunchKernelGGL(k_ref_box, dim3((n + 255) / 256), dim3(256), 0, ws(s).stream, s->w_io[0].as<float>(), s->w_io[1].as<float>(), n,
                      bmin[0], bmin[1], bmin[2], bmax[0], bmax[1], bmax[2], s->w_io[2].as<float>());
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipStreamSynchronize(ws(s).stream));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(t, s->w_io[2].p, (size_t)n * 4, hipMemcpyDeviceToHost));
   return RTX_OK;
@@ -1304,17 +1375,17 @@ extern "C" int rtx_debug_hit(rtx_scene* s, const float* o, const float* d, uint3
   if (int rc = s->w_io[3].ensure((size_t)n * 4)) return rc;
   if (int rc = s->w_io[4].ensure(b3)) return rc;
   if (int rc = s->w_io[5].ensure(std::max<size_t>(1, (size_t)n * nleaf))) return rc;
-  if (int rc = s->w_rays[0].ensure((size_t)n * 32)) return rc;
-  HIP_TRY(hipMemcpyAsync(s->w_io[0].p, o, b3, hipMemcpyHostToDevice, s->stream));
-  HIP_TRY(hipMemcpyAsync(s->w_io[1].p, d, b3, hipMemcpyHostToDevice, s->stream));
-  if (box_flags) HIP_TRY(hipMemsetAsync(s->w_io[5].p, 0, std::max<size_t>(1, (size_t)n * nleaf), s->stream));
-  hipLaunchKernelGGL(k_make_rays, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->w_io[0].as<float>(), s->w_io[1].as<float>(), n,
-                     s->w_rays[0].as<float4>());
+  if (int rc = ws(s).w_rays[0].ensure((size_t)n * 32)) return rc;
+  HIP_TRY(hipMemcpyAsync(s->w_io[0].p, o, b3, hipMemcpyHostToDevice, ws(s).stream));
+  HIP_TRY(hipMemcpyAsync(s->w_io[1].p, d, b3, hipMemcpyHostToDevice, ws(s).stream));
+  if (box_flags) HIP_TRY(hipMemsetAsync(s->w_io[5].p, 0, std::max<size_t>(1, (size_t)n * nleaf), ws(s).stream));
+  hipLaunchKernelGGL(k_make_rays, dim3((n + 255) / 256), dim3(256), 0, ws(s).stream, s->w_io[0].as<float>(), s->w_io[1].as<float>(), n,
+                     ws(s).w_rays[0].as<float4>());
   // outputs: t -> io[2], face -> io[3], normal -> io[0], point -> io[4] (the xyz inputs are consumed by k_make_rays first)
-  hipLaunchKernelGGL(k_debug_hit, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->dev, s->w_rays[0].as<float4>(), n,
+  hipLaunchKernelGGL(k_debug_hit, dim3((n + 255) / 256), dim3(256), 0, ws(s).stream, s->dev, ws(s).w_rays[0].as<float4>(), n,
                      s->w_io[2].as<float>(), s->w_io[3].as<int>(), s->w_io[0].as<float>(), s->w_io[4].as<float>(),
                      box_flags ? s->w_io[5].as<unsigned char>() : nullptr);
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipStreamSynchronize(ws(s).stream));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(t, s->w_io[2].p, (size_t)n * 4, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(face, s->w_io[3].p, (size_t)n * 4, hipMemcpyDeviceToHost));

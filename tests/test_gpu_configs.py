@@ -124,10 +124,10 @@ def test_config3_hall_shadow_queries_vs_oracle(api, oa, hall):
 
 
 def lost_nodes(lost, st):
-    """Shadow rays not traced = nodes that missed; a lost reflection ray also takes its descendants with it, so
-    the exact figure lies between lost / 3 (all lost at the first bounce) and lost (all at the last)."""
+    """With m_g nodes of generation g missing: reflection rays not spawned = 2 m1 + m2, shadow rays not traced =
+    3 m1 + 2 m2 + m3 (a node that misses takes its descendants with it)."""
     missing = 4 * int(st.rays_primary) - int(st.rays_shadow)
-    assert (lost + 2) // 3 <= missing <= lost, (lost, missing)
+    assert lost <= missing < 4 * lost + 3000, (lost, missing)
     return missing
 
 
