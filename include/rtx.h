@@ -173,6 +173,18 @@ int rtx_trace_closest(rtx_scene*, const float* origin_xyz, const float* dir_xyz,
 int rtx_trace_closest_dev(rtx_scene*, const float* origin_xyz, const float* dir_xyz, uint32_t n,
                           float* t, int32_t* face_id);
 
+/* rtx_trace_closest_dev for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same
+ * kernels and results, but the ray records, hit records and traversal-stack overflow that
+ * rtx_trace_closest_dev keeps in the scene's growable workspace live in a fixed device array inside
+ * the library (~11.7 MB per GPU, held until the process ends), and the call makes no hipMalloc /
+ * hipFree / event creation.  At most RTX_NOALLOC_MAX_RAYS rays per call (RTX_ELIMIT beyond).  All
+ * calls on one GPU share that array, whichever scene they name: calls that overlap on a GPU race;
+ * serialise them.  Returns when the results are in t / face_id (device pointers, like the inputs). */
+#define RTX_NOALLOC_MAX_RAYS 65536u
+int rtx_trace_closest_noalloc(rtx_scene*, const float* origin_xyz, const float* dir_xyz, uint32_t n,
+                              float* t, int32_t* face_id);
+
 /* Flyscene::canSeeLight(lightPos, position) for n pairs (src/flyscene.cpp:747-782).
  * blocker_material: material id the reference would return, -1 for the default Mtl. */
 int rtx_trace_visible(rtx_scene*, const float* light_xyz, const float* position_xyz, uint32_t n,

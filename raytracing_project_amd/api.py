@@ -52,8 +52,9 @@ SYMBOLS = ["rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_
            "rtx_trace_visible", "rtx_render", "rtx_render_dev", "rtx_render_dev_enqueue", "rtx_render_finish", "rtx_tiles_count", "rtx_render_tiles_dev", "rtx_render_tiles_dev_enqueue", "rtx_tiles_assemble_dev",
            "rtx_get_stats", "rtx_scene_build_reference_leafboxes", "rtx_scene_set_leafboxes",
            "rtx_scene_get_leafboxes", "rtx_intersect_box", "rtx_trace_shade", "rtx_camera_points", "rtx_scene_set_flags",
-           "rtx_scene_get_packed_bvh", "rtx_debug_hit"]
+           "rtx_scene_get_packed_bvh", "rtx_debug_hit", "rtx_trace_closest_noalloc"]
 
+NOALLOC_MAX_RAYS = 65536
 FLAG_NO_ROOT_GATE, FLAG_SCHED_REFILL, FLAG_SCHED_GROUPS, FLAG_SCHED_SPLIT = 1, 2, 4, 8
 
 _lib = None
@@ -101,6 +102,7 @@ def lib():
         L.rtx_scene_get_bvh.argtypes = [C.c_void_p, _u, _u]
         L.rtx_trace_closest.argtypes = [C.c_void_p, _f, _f, C.c_uint32, _f, _i, _f, _f, _i]
         L.rtx_trace_closest_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.rtx_trace_closest_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.rtx_trace_visible.argtypes = [C.c_void_p, _f, _f, C.c_uint32, C.POINTER(C.c_uint8), _i]
         L.rtx_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Options), Rect, _f, _f, _i]
         L.rtx_render_dev.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Options), Rect, C.c_void_p,
@@ -303,6 +305,10 @@ class Scene:
 
     def trace_closest_dev(self, o_ptr, d_ptr, n, t_ptr, face_ptr):
         _check(lib().rtx_trace_closest_dev(self.h, o_ptr, d_ptr, n, t_ptr, face_ptr))
+
+    def trace_closest_noalloc(self, o_ptr, d_ptr, n, t_ptr, face_ptr):
+        """rtx_trace_closest_noalloc: device pointers, at most NOALLOC_MAX_RAYS rays, no allocation inside."""
+        _check(lib().rtx_trace_closest_noalloc(self.h, o_ptr, d_ptr, n, t_ptr, face_ptr))
 
     def trace_visible(self, light, pos):
         light = np.ascontiguousarray(light, np.float32).reshape(-1, 3)

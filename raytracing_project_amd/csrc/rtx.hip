@@ -153,6 +153,7 @@ struct rtx_scene {
 static rtx_scene::Call& cur_call(rtx_scene* s) { return s->calls[s->cur]; }
 static rtx_scene::Slot& ws(rtx_scene* s) { return s->slots[s->cur]; }          // the workspace of the current call
 static int finish_call(rtx_scene* s, rtx_scene::Call& c);
+static int scratch_init(int device);
 static int trace_grid(const rtx_scene* s) { return s->ncu * 8; }      // 8 blocks x 4 waves = 32 waves per CU
 
 extern "C" const char* rtx_last_error(void) { return g_err.c_str(); }
@@ -480,6 +481,7 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   // that calls in flight never share one)
   for (rtx_scene::Slot& w : s->slots) if (!w.stream) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
   for (rtx_scene::Slot& w : s->slots) if (!w.stream2) HIP_TRY(hipStreamCreateWithFlags(&w.stream2, hipStreamNonBlocking));
+  if (int rc = scratch_init(device)) return rc;
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   s->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1409,6 +1411,69 @@ extern "C" int rtx_render(rtx_scene* s, const rtx_camera* cam, const rtx_options
   if (rgb) HIP_TRY(hipMemcpy(rgb, s->w_io[0].p, npix * 12, hipMemcpyDeviceToHost));
   if (t) HIP_TRY(hipMemcpy(t, s->w_io[1].p, npix * 4, hipMemcpyDeviceToHost));
   if (face) HIP_TRY(hipMemcpy(face, s->w_io[2].p, npix * 4, hipMemcpyDeviceToHost));
+  return RTX_OK;
+}
+
+// ------------------------------------------------------------------ the entry point that allocates nothing
+// rtx_trace_closest_dev for callers that cannot allocate (HIP graph capture, tight serving loops, harnesses that
+// forbid hipMalloc): the same kernels, with the ray records, the hit records, the ray count and the overflow
+// columns of the traversal stacks in a file-scope device array instead of the scene's growable workspace.
+// Every GPU the library runs on holds its own copy of the array until the process ends; g_scratch_ptr[device]
+// is that copy's device address (hipGetSymbolAddress at rtx_scene_commit, with the device current) -- the
+// array's name is only a host-side stand-in and is never handed to a kernel or a memset.
+constexpr uint32_t kNoAllocMaxRays = RTX_NOALLOC_MAX_RAYS;
+constexpr uint32_t kNoAllocBlocks = 256;                                  // grid cap: sizes the overflow columns
+constexpr size_t kScratchRaysOff = 0;                                     // 32 B per ray
+constexpr size_t kScratchHitsOff = kScratchRaysOff + (size_t)kNoAllocMaxRays * 32;     // 8 B per ray
+constexpr size_t kScratchCountOff = kScratchHitsOff + (size_t)kNoAllocMaxRays * 8;     // the ray count the queue kernel reads
+constexpr size_t kScratchOvfOff = kScratchCountOff + 256;
+constexpr size_t kScratchBytes = kScratchOvfOff + (size_t)kNoAllocBlocks * kBlock * (kStackDepth - kLdsStack) * 4;   // ~11.7 MB
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+constexpr int kMaxDevices = 64;
+static unsigned char* g_scratch_ptr[kMaxDevices] = {};
+
+// Called by rtx_scene_commit with `device` current: once per device.
+static int scratch_init(int device) {
+  if (device < 0 || device >= kMaxDevices) return fail(RTX_ELIMIT, "device index %d beyond %d", device, kMaxDevices);
+  if (g_scratch_ptr[device]) return RTX_OK;
+  void* p = nullptr;
+  HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+  g_scratch_ptr[device] = (unsigned char*)p;
+  return RTX_OK;
+}
+
+__global__ void k_store_u32(uint32_t* p, uint32_t v) { if (blockIdx.x == 0 && threadIdx.x == 0) *p = v; }
+
+extern "C" int rtx_trace_closest_noalloc(rtx_scene* s, const float* o, const float* d, uint32_t n, float* t, int32_t* face) {
+  if (int rc = check_ready(s)) return rc;
+  if (n == 0) return RTX_OK;
+  if (!o || !d) return fail(RTX_EINVAL, "null ray arrays");
+  if (n > kNoAllocMaxRays)
+    return fail(RTX_ELIMIT, "rtx_trace_closest_noalloc takes at most %u rays per call (got %u): its scratch buffer is a fixed device array", kNoAllocMaxRays, n);
+  unsigned char* base = g_scratch_ptr[s->device];
+  if (!base) return fail(RTX_ESTATE, "no scratch address for device %d (rtx_scene_commit looks it up)", s->device);
+  float4* rays = (float4*)(base + kScratchRaysOff);
+  uint2* hits = (uint2*)(base + kScratchHitsOff);
+  uint32_t* count = (uint32_t*)(base + kScratchCountOff);
+  uint32_t* ovf = (uint32_t*)(base + kScratchOvfOff);
+  // Nothing here needs to start at zero: the count and the records of rays [0, n) are written before they are read,
+  // every ray writes its hit record, and a stack column is written before it is read.  What the last call left
+  // beyond n is never looked at.
+  hipStream_t st = ws(s).stream;
+  const uint32_t blocks = (n + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(k_store_u32, dim3(1), dim3(64), 0, st, count, n);
+  hipLaunchKernelGGL(k_make_rays, dim3(blocks), dim3(256), 0, st, o, d, n, rays);
+  const uint32_t grid = std::min<uint32_t>(blocks, kNoAllocBlocks);
+  // the scheduler: what the scene's flags force, else the heuristic's pick for queued rays (no tuner trial here)
+  if (s->flags & RTX_FLAG_SCHED_GROUPS)
+    hipLaunchKernelGGL(k_trace_queue<false>, dim3(grid), dim3(kBlock), 0, st, s->dev, rays, count, 1u, 0u, grab_size(), 1u, ovf, hits);
+  else
+    hipLaunchKernelGGL(k_trace_queue<true>, dim3(grid), dim3(kBlock), 0, st, s->dev, rays, count, 1u, 0u, grab_size(),
+                       (s->flags & RTX_FLAG_SCHED_SPLIT) ? kTriMinSplit : 1u, ovf, hits);
+  hipLaunchKernelGGL(k_unpack_hits, dim3(blocks), dim3(256), 0, st, s->dev, rays, hits, n, t, face, (float*)nullptr, (float*)nullptr,
+                     (int*)nullptr);
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
   return RTX_OK;
 }
 
