@@ -341,6 +341,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "triangles": int(info.ntris), "bvh_nodes": int(info.nnodes),
+                       "bvh_build_ms_host": float(info.build_ms), "scene_device_bytes": int(info.device_bytes),
+                       "triangles_outside_bvh": int(info.nwild),
                        "image": [W, H], "lights": len(wl["lights"]), "spp": wl["spp"], "max_bounces": wl["opts"][0],
                        "tile": TILE, "partition": (("image tiles round-robin over %d ranks, scene replicated, RGB gathered to rank 0" % world) if world > 1
                                      else "one rank renders the whole frame row-major") + (("; %d frames in flight (rtx_render_*_enqueue / rtx_render_finish)" % args.inflight) if pipelined else ""),
@@ -365,6 +367,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_roofline:
         result["config"]["kernel_ms_per_frame_one_at_a_time"] = {"trace_camera": ms_iso[0], "trace_queue": ms_iso[1], "all_kernels": ms_iso[2]}
         result["roofline"] = roofline(args, wl, scene, info, ms_iso, rays_tot / args.steps)
+        ent = result["roofline"]["rays_entering_bvh_per_frame"]
+        # rays that pass the reference's root-box gate and walk the hierarchy (the rest end at the gate: the camera of
+        # SURVEY 8(d) sees past the soup on more than half of the frame)
+        result["config"]["rays_entering_bvh_per_frame"] = ent
+        result["mrays_per_s_entering_bvh"] = (ent["primary"] + ent["shadow"] + result["config"]["rays_per_frame"]["reflection"]) / (dt / args.steps) / 1e6
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, wl)
     if rank == 0:
@@ -417,8 +424,35 @@ def oracle_scene(wl):
     return oa, s
 
 
+PMC_FILE = os.path.join("profiles", "r02_pmc.json")     # scripts/prof_derive.py --pmc-json over this round's rocprofv3 passes
+
+
+def any_blocker_shadows(wl):
+    """librtx stops a shadow ray at any blocker when every material shades a blocked light alike (rtx.hip, commit)."""
+    m = wl["mats"]
+    if not m:
+        return False
+    key = lambda d: tuple((k, tuple(np.ravel(d.get(k, dflt)).tolist())) for k, dflt in
+                          (("ka", (.3, .3, .3)), ("kd", (.5, .5, .5)), ("ks", (1., 1., 1.)), ("ns", 10.0), ("d", 1.0)))
+    tm = np.asarray(wl["tri_mat"])
+    return all(key(x) == key(m[0]) for x in m) and bool((tm >= 0).all() and (tm < len(m)).all())
+
+
 def roofline(args, wl, scene, info, ms, rays):
-    """Algorithmic bytes of the dominant traversal kernel / its measured duration vs HBM peak."""
+    """The dominant traversal kernel against the rooflines that could bound it.
+
+    ms: per-frame kernel durations measured one frame at a time (HIP events on the library's stream).
+    * algorithmic_bytes_per_launch: SURVEY 8(d)'s figure, 32 B per node visited + 36 B per triangle tested + io,
+      counted by the CPU mirror (oracle/rt_oracle_bvh.c) walking the same BVH in the same order on every k-th
+      pixel's rays (shadow rays bounded at the light and stopped at any blocker exactly where the kernel does).
+      It is LOAD DEMAND: nearly all of it is served by L1 / L2 / Infinity Cache, so demand / duration may exceed
+      the HBM peak and is reported as `load_demand`, not as a fraction of HBM.
+    * achieved / frac (bound "hbm"): the bytes that did cross the HBM-side interface per launch (`traffic`, PMC
+      FETCH_SIZE x2 + WRITE_SIZE from this round's rocprofv3 passes of this command) / the launch duration
+      measured here, against 8 TB/s; without a PMC record, the compulsory bytes (scene + io touched once).
+    * valu: the bound that binds -- VALU-busy share of the kernel's SIMD cycles x active lanes per VALU
+      instruction (same PMC passes): the fraction of the vector ALU's lane-cycles doing useful work.
+    """
     oa, osc = oracle_scene(wl)
     W, H = wl["W"], wl["H"]
     stride = max(1, args.roofline_stride)
@@ -428,69 +462,87 @@ def roofline(args, wl, scene, info, ms, rays):
     ocam = oa.make_camera(wl["view"], W, H)
     o, d1 = oa.camera_rays(ocam, (0, 0, W, H))
     pick = np.arange(0, W * H, stride)
-    threads = min(16, os.cpu_count() or 1)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = min(16, cores)
     t_cpu0 = time.perf_counter()
     t, f, nv, tt, gs, tf = oa.bvh_trace(nodes, tris, order, lo, hi, o[pick], d1[pick], threads=threads, nwild=info.nwild,
                                         layout_counts=True)
     cpu_bvh_s = time.perf_counter() - t_cpu0
     prim_bytes = (32.0 * nv.sum() + 36.0 * tt.sum()) * stride + 8.0 * W * H
-    # what the device layout really has to load: 64-B packed groups, 16 B for a triangle's plane
-    # stage, 48 B more when it goes on to the barycentrics, 8 B result
-    prim_layout_bytes = (64.0 * gs.sum() + 16.0 * tt.sum() + 48.0 * tf.sum()) * stride + 8.0 * W * H
-    res = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
-           "bytes_model": "32 B/node visited + 36 B/triangle tested + io (8 B/primary, 72 B/queued ray), counts from the CPU "
-                          "mirror traversal of the same BVH on every %d-th pixel, scaled" % stride,
-           "per_ray": {"primary_nodes": float(nv.mean()), "primary_tris": float(tt.mean())}}
-    # shadow rays of the sampled pixels that hit something (first light only; scaled by the light count)
+    # what the device layout really loads: 64-B packed groups, 16 B for a triangle's plane stage, 48 B more when it
+    # goes on to the barycentrics, 8 B result
+    prim_layout = (64.0 * gs.sum() + 16.0 * tt.sum() + 48.0 * tf.sum()) * stride + 8.0 * W * H
+    entering = {"primary": int((gs > 0).sum()) * stride, "shadow": 0}
+    per_ray = {"primary_nodes": float(nv.mean()), "primary_tris": float(tt.mean()),
+               "primary_nodes_of_rays_entering_bvh": float(nv[gs > 0].mean()) if (gs > 0).any() else 0.0}
     hit = f >= 0
-    sh_bytes = 0.0
+    sh_bytes = sh_layout = 0.0
+    anyhit = any_blocker_shadows(wl)
     if hit.any() and wl["opts"][4]:
-        # hit points / shadow directions in numpy fp32: ulp-level differences from the kernel's
-        # own values do not move the visit counts
+        # hit points / shadow directions in numpy fp32: ulp-level differences from the kernel's own values do not
+        # move the visit counts.  First light only, scaled by the light count.
         dd = d1[pick][hit]
         d2 = dd / np.sqrt((dd * dd).sum(1, dtype=np.float32))[:, None]
         P = (o[pick][hit] + t[hit, None] * d2).astype(np.float32)
         L = np.float32(wl["lights"][0])
         sd = (L[None] - P).astype(np.float32)
-        sd1 = (sd / np.sqrt((sd * sd).sum(1, dtype=np.float32))[:, None]).astype(np.float32)
-        _, _, nv2, tt2 = oa.bvh_trace(nodes, tris, order, lo, hi, P, sd1, threads=threads, nwild=info.nwild)
+        dist = np.sqrt((sd * sd).sum(1, dtype=np.float32)).astype(np.float32)
+        sd1 = (sd / dist[:, None]).astype(np.float32)
+        tmax = (dist * np.float32(1.001)).astype(np.float32)             # shadow_tmax(), rtx_kernels.h
+        _, _, nv2, tt2, gs2, tf2 = oa.bvh_trace_shadow(nodes, tris, order, lo, hi, P, sd1, tmax, anyhit, threads=threads, nwild=info.nwild)
         nl = len(wl["lights"])
         sh_bytes = ((32.0 * nv2.sum() + 36.0 * tt2.sum()) + 72.0 * len(P)) * stride * nl
-        res["per_ray"].update({"shadow_nodes": float(nv2.mean()), "shadow_tris": float(tt2.mean())})
+        sh_layout = ((64.0 * gs2.sum() + 16.0 * tt2.sum() + 48.0 * tf2.sum()) + 72.0 * len(P)) * stride * nl
+        entering["shadow"] = int((gs2 > 0).sum()) * stride * nl
+        per_ray.update({"shadow_nodes": float(nv2.mean()), "shadow_tris": float(tt2.mean()),
+                        "shadow_rays_stop_at_any_blocker": bool(anyhit)})
     spp = wl["spp"]
-    cand = [("k_trace_camera", prim_bytes * spp, ms[0]), ("k_trace_queue(shadow)", sh_bytes * spp, ms[1])]
+    cand = [("k_trace_camera", prim_bytes, prim_layout, ms[0] / spp), ("k_trace_queue", sh_bytes, sh_layout, ms[1] / spp)]
     if wl["opts"][0] > 0:     # reflection launches share k_trace_queue's time; only the camera kernel is attributable
         cand = cand[:1]
-    name, nbytes, kms = max(cand, key=lambda c: c[2])
-    launches = spp if name == "k_trace_camera" else spp
-    res.update({"kernel": name, "achieved": nbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0,
-                "algorithmic_bytes_per_launch": nbytes / launches, "avg_launch_ms": kms / launches})
-    res["frac"] = res["achieved"] / HBM_PEAK_GBS
-    # compulsory floor: the scene and the framebuffer touched once
+    name, nbytes, lbytes, kms = max(cand, key=lambda c: c[3])
     scene_bytes = 64.0 * (info.nnodes / 4.0) + 64.0 * info.ntris + 4.0 * info.ntris
-    res["compulsory_bytes_per_frame"] = scene_bytes + 20.0 * W * H
-    # the same traversal of the same BVH on the host's cores (the "same algorithm on the CPU" figure of SURVEY 8(d))
-    res["cpu_bvh_traversal"] = {"value": len(pick) / cpu_bvh_s / 1e6, "unit": "Mrays/s (primary)", "cores": threads,
-                                "sample": "every %d-th pixel's primary ray, oracle/rt_oracle_bvh.c" % stride}
-    if name == "k_trace_camera" and kms > 0:
-        # the same launch priced by the bytes of the device layout instead of SURVEY 8(d)'s model
-        res["layout_bytes_per_launch"] = prim_layout_bytes * spp / launches
-        res["achieved_layout_bytes"] = prim_layout_bytes * spp / (kms * 1e-3) / 1e9
-        res["frac_layout_bytes"] = res["achieved_layout_bytes"] / HBM_PEAK_GBS
-        res["note"] = ("both figures are load demand, not HBM traffic: the scene is cache resident (see traffic), "
-                       "so frac may exceed 1; the kernel's real bound is vector-ALU issue (84 % busy, profiles/r01_soup1M_4k_final.txt; DESIGN.md 5)")
-    # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this
-    # process, so the figure comes from the committed rocprofv3 --pmc passes of this same
-    # command (profiles/r01_traffic.json, corrected as MI355X_MICROARCH.md prescribes).
+    io_bytes = 8.0 * W * H if name == "k_trace_camera" else 40.0 * rays[1] / spp
+    compulsory = scene_bytes + io_bytes
+    pmc = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            tr = json.load(f).get(args.workload, {})
-        key = "k_trace_camera" if name == "k_trace_camera" else "k_trace_queue"
-        if key in tr:
-            res["traffic"] = tr[key]["hbm_bytes_per_launch"]
-            res["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits included)"
+        with open(os.path.join(ROOT, PMC_FILE)) as fh:
+            pmc = json.load(fh).get(args.workload, {}).get(name, {})
     except (OSError, ValueError):
         pass
+    traffic = pmc.get("hbm_bytes_per_launch")
+    sec = kms * 1e-3
+    hbm_bytes = traffic if traffic is not None else compulsory
+    res = {"bound": "hbm", "kernel": name, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+           "achieved": hbm_bytes / sec / 1e9 if sec > 0 else 0.0,
+           "traffic": traffic, "avg_launch_ms": kms,
+           "achieved_is": ("HBM-side bytes per launch (traffic: PMC FETCH_SIZE x2 + WRITE_SIZE, %s) / the launch duration measured in this run"
+                           % PMC_FILE) if traffic is not None else "compulsory bytes per launch (no PMC record for this workload) / measured launch duration",
+           "compulsory_bytes_per_launch": compulsory,
+           "algorithmic_bytes_per_launch": nbytes,
+           "bytes_model": "SURVEY 8(d): 32 B/node visited + 36 B/triangle tested + io (8 B/primary, 72 B/queued ray); counts from the CPU "
+                          "mirror traversal of the same BVH on every %d-th pixel's rays, scaled" % stride,
+           "per_ray": per_ray}
+    res["frac"] = res["achieved"] / HBM_PEAK_GBS
+    # the 8(d) bytes are load demand served by the caches: set against the L2's aggregate bandwidth, never against HBM
+    L2_PEAK_GBS = 34500.0           # MI355X_MICROARCH.md: 8 x 4 MiB L2, ~34.5 TB/s aggregate
+    res["load_demand"] = {"GB/s": nbytes / sec / 1e9 if sec > 0 else 0.0, "device_layout_GB/s": lbytes / sec / 1e9 if sec > 0 else 0.0,
+                          "device_layout_bytes_per_launch": lbytes,
+                          "frac_of_l2_peak": (lbytes / sec / 1e9 / L2_PEAK_GBS) if sec > 0 else 0.0, "l2_peak_GB/s": L2_PEAK_GBS,
+                          "note": "served by L1 / L2 / Infinity Cache (scene resident: see traffic); not an HBM figure"}
+    if traffic is not None:
+        res["traffic_over_compulsory"] = traffic / compulsory
+    if "valu_busy" in pmc and "active_lanes" in pmc:
+        res["valu"] = {"bound": "valu", "busy": pmc["valu_busy"], "active_lanes": pmc["active_lanes"],
+                       "frac": pmc["valu_busy"] * pmc["active_lanes"],
+                       "waves_per_simd": pmc.get("waves_per_simd"), "ta_busy": pmc.get("ta_busy"), "td_busy": pmc.get("td_busy"),
+                       "note": "the bound that binds: share of the kernel's SIMD cycles issuing vector ALU instructions x active lanes "
+                               "per instruction (%s, rocprofv3 --pmc SQ passes of this command with --inflight 1)" % PMC_FILE}
+        res["binding_bound"] = "valu"
+    res["rays_entering_bvh_per_frame"] = {k: v * spp for k, v in entering.items()}
+    # the same traversal of the same BVH on the host's cores (the "same algorithm on the CPU" figure of SURVEY 8(d))
+    res["cpu_bvh_traversal"] = {"value": len(pick) / cpu_bvh_s / 1e6, "unit": "Mrays/s (primary)", "cores": threads, "host_cores": cores,
+                                "sample": "every %d-th pixel's primary ray, oracle/rt_oracle_bvh.c" % stride}
     return res
 
 
@@ -500,7 +552,8 @@ def cpu_baseline(args, wl):
     W, H = wl["W"], wl["H"]
     ntri = len(wl["idx"])
     # ~15 s of work at ~6e7 triangle tests / s / core
-    cores = min(16, os.cpu_count() or 1)
+    host_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(16, host_cores)
     budget = 6e7 * cores * 12.0
     n = int(max(256, min(args.cpu_sample * 64, budget / max(ntri, 1) / 1.6)))
     n = min(n, W * H)
@@ -520,7 +573,7 @@ def cpu_baseline(args, wl):
             osc.closest(P, sd, threads=cores)                    # shadow rays: closest hit, as canSeeLight does
             nrays += len(P)
     dt = time.perf_counter() - t0
-    return {"value": nrays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+    return {"value": nrays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "host_cores_available": host_cores, "kind": "port",
             "sample": "%d primary rays (every %d-th pixel) + %d shadow rays of %s, brute force over %d triangles "
                       "(reference algorithm, oracle/rt_oracle.c), %.1f s" % (len(pick), stride, nrays - len(pick),
                                                                              args.workload, ntri, dt)}

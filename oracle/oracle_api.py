@@ -152,6 +152,31 @@ def bvh_trace(nodes8, tri16, tri_face, root_lo, root_hi, o, d1, threads=1, nwild
     return t, face, nv, tt
 
 
+def bvh_trace_shadow(nodes8, tri16, tri_face, root_lo, root_hi, o, d1, tmax, anyhit, threads=1, nwild=0):
+    """Shadow-queue rays as the device walks them (bounded at tmax, optionally stopping at any blocker clearly before
+    the light): (t, face, nodes_visited, tris_tested, group_steps, tris_full)."""
+    nodes8 = np.ascontiguousarray(nodes8, np.uint32)
+    tri16 = np.ascontiguousarray(tri16, np.float32)
+    tri_face = np.ascontiguousarray(tri_face, np.int32)
+    o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+    d1 = np.ascontiguousarray(d1, np.float32).reshape(-1, 3)
+    tmax = np.ascontiguousarray(tmax, np.float32)
+    rl = np.ascontiguousarray(root_lo, np.float32)
+    rh = np.ascontiguousarray(root_hi, np.float32)
+    n = len(o)
+    t = np.zeros(n, np.float32)
+    face = np.zeros(n, np.int32)
+    nv, tt, gs, tf = (np.zeros(n, np.uint32) for _ in range(4))
+    u32 = C.POINTER(C.c_uint32)
+    L = lib()
+    L.ora_bvh_trace_shadow.restype = None
+    L.ora_bvh_trace_shadow(nodes8.ctypes.data_as(u32), fp(tri16), tri_face.ctypes.data_as(C.POINTER(C.c_int32)),
+                           C.c_uint32(len(tri_face)), C.c_uint32(nwild), fp(rl), fp(rh), fp(o), fp(d1), fp(tmax), C.c_int(1 if anyhit else 0),
+                           C.c_int(n), C.c_int(threads), fp(t), face.ctypes.data_as(C.POINTER(C.c_int32)), nv.ctypes.data_as(u32),
+                           tt.ctypes.data_as(u32), gs.ctypes.data_as(u32), tf.ctypes.data_as(u32))
+    return t, face, nv, tt, gs, tf
+
+
 def camera_rays(cam, rect):
     x0, y0, x1, y1 = rect
     n = (x1 - x0) * (y1 - y0)

@@ -36,6 +36,8 @@ typedef struct {
   float* t; int32_t* face; uint32_t* nodes_visited; uint32_t* tris_tested;
   uint8_t* ev; uint32_t ev_stride; uint32_t* nev;   /* optional step log (wave-scheduling studies) */
   uint32_t* group_steps; uint32_t* tris_full;       /* optional: 64-byte group fetches, triangle tests that went past the plane stage */
+  const float* tmax; int anyhit;                    /* optional: shadow-queue rays as k_trace_queue walks them (bounded at tmax; any blocker
+                                                       clearly before the light ends the walk), rtx_kernels.h QueueSource */
 } bvh_job;
 
 /* reference root gate: Intersect::BoxObject::intersects (src/Intersect.cpp:67-145) */
@@ -94,7 +96,8 @@ static void* bvh_worker(void* arg) {
     const float* o = j->o + 3 * i;
     float d[3];
     normalize3f(j->d1 + 3 * i, d);
-    float best_t = INFINITY; int best_id = -1;
+    const float tmax = j->tmax ? j->tmax[i] : INFINITY;
+    float best_t = tmax; int best_id = -1;
     uint32_t nv = 0, tt = 0, ne = 0, gs = 0, tf = 0;
     uint8_t* ev = j->ev ? j->ev + (size_t)i * j->ev_stride : NULL;
     if (j->ntris && gate(o, d, j->root_lo, j->root_hi) != INFINITY) {
@@ -137,12 +140,13 @@ static void* bvh_worker(void* arg) {
           if (ev && ne < j->ev_stride) ev[ne] = (uint8_t)(cnt | (best_id != -1 ? 0x80 : 0));
           ++ne;
           for (uint32_t k = first; k < first + cnt; ++k) { ++tt; tf += (uint32_t)tri_test(j, k, o, d, &best_t, &best_id); }
+          if (j->anyhit && best_id != -1 && best_t < 0.998f * tmax) break;
         }
         if (sp == 0) break;
         cur = stack[--sp];
       }
     }
-    j->t[i] = best_t; j->face[i] = best_id;
+    j->t[i] = best_id == -1 ? INFINITY : best_t; j->face[i] = best_id;
     if (j->nodes_visited) j->nodes_visited[i] = nv;
     if (j->tris_tested) j->tris_tested[i] = tt;
     if (j->nev) j->nev[i] = ne;
@@ -154,6 +158,8 @@ static void* bvh_worker(void* arg) {
 
 static uint32_t* g_group_steps = NULL;
 static uint32_t* g_tris_full = NULL;
+static const float* g_tmax = NULL;
+static int g_anyhit = 0;
 /* d1 = the direction a Ray object holds (already normalised once); triangles only, no spheres. */
 void ora_bvh_trace(const uint32_t* nodes8, const float* tri16, const int32_t* tri_face, uint32_t ntris, uint32_t nwild,
                    const float* root_lo, const float* root_hi, const float* o, const float* d1, int n, int threads,
@@ -169,6 +175,7 @@ void ora_bvh_trace(const uint32_t* nodes8, const float* tri16, const int32_t* tr
     j->nodes_visited = nodes_visited; j->tris_tested = tris_tested;
     j->ev = NULL; j->ev_stride = 0; j->nev = NULL;
     j->group_steps = g_group_steps; j->tris_full = g_tris_full;
+    j->tmax = g_tmax; j->anyhit = g_anyhit;
   }
   if (threads == 1) { bvh_worker(&jobs[0]); return; }
   for (int i = 0; i < threads; ++i) pthread_create(&th[i], NULL, bvh_worker, &jobs[i]);
@@ -185,6 +192,18 @@ void ora_bvh_trace2(const uint32_t* nodes8, const float* tri16, const int32_t* t
   g_group_steps = NULL; g_tris_full = NULL;
 }
 
+/* Shadow-queue rays as the device walks them: ray i starts pruned at tmax[i] (1.001 |light - P|, shadow_tmax() in
+ * rtx_kernels.h) and, with anyhit, stops at the first leaf that leaves it a hit below 0.998 tmax[i].  Counts only
+ * (bench.py's byte accounting): which blocker is reported depends on the order, the visible / blocked answer does not. */
+void ora_bvh_trace_shadow(const uint32_t* nodes8, const float* tri16, const int32_t* tri_face, uint32_t ntris, uint32_t nwild,
+                          const float* root_lo, const float* root_hi, const float* o, const float* d1, const float* tmax, int anyhit, int n,
+                          int threads, float* t, int32_t* face, uint32_t* nodes_visited, uint32_t* tris_tested, uint32_t* group_steps,
+                          uint32_t* tris_full) {
+  g_tmax = tmax; g_anyhit = anyhit;
+  ora_bvh_trace2(nodes8, tri16, tri_face, ntris, nwild, root_lo, root_hi, o, d1, n, threads, t, face, nodes_visited, tris_tested, group_steps, tris_full);
+  g_tmax = NULL; g_anyhit = 0;
+}
+
 /* Step log of the same traversal: ev[i*stride + s] & 0x7f = 0 for a node-group step, k > 0 for a leaf
  * step over k triangles; bit 0x80 = a hit had already been found when the step ran; nev[i] = number of steps (may exceed stride: then the log is cut). */
 void ora_bvh_trace_events(const uint32_t* nodes8, const float* tri16, const int32_t* tri_face, uint32_t ntris, uint32_t nwild,
@@ -194,7 +213,7 @@ void ora_bvh_trace_events(const uint32_t* nodes8, const float* tri16, const int3
   j.nodes = nodes8; j.tris = tri16; j.tri_face = tri_face; j.ntris = ntris; j.nwild = nwild; j.root_lo = root_lo; j.root_hi = root_hi;
   j.o = o; j.d1 = d1; j.n = n; j.tid = 0; j.nthreads = 1; j.t = t; j.face = face; j.nodes_visited = NULL; j.tris_tested = NULL;
   j.ev = ev; j.ev_stride = stride; j.nev = nev;
-  j.group_steps = NULL; j.tris_full = NULL;
+  j.group_steps = NULL; j.tris_full = NULL; j.tmax = NULL; j.anyhit = 0;
   bvh_worker(&j);
 }
 

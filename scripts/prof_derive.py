@@ -34,8 +34,45 @@ def main():
         i = args.index("--traffic-json")
         want_json = args[i + 1]
         del args[i:i + 2]
+    pmc_json = None
+    if "--pmc-json" in args:
+        i = args.index("--pmc-json")
+        pmc_json = args[i + 1]
+        del args[i:i + 2]
     d = load(args)
     kernels = sorted({k for k, _ in d if k.startswith("k_")})
+    if pmc_json:
+        # what bench.py's roofline reads (profiles/rNN_pmc.json): per kernel, HBM-side bytes per launch and the
+        # vector-ALU figures; of a kernel's template variants the one that issued more VALU instructions counts
+        out = {}
+        for k in kernels:
+            g = lambda c: d.get((k, c))  # noqa: E731
+            name = k.split("<")[0]
+            rec = {}
+            if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+                rec.update({"fetch_kb_raw": g("FETCH_SIZE"), "write_kb_raw": g("WRITE_SIZE"),
+                            "hbm_bytes_per_launch": (2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024})
+            if g("SQ_BUSY_CYCLES") and g("SQ_INSTS_VALU"):
+                busy = g("SQ_BUSY_CYCLES") / NSE
+                rec["valu_insts"] = g("SQ_INSTS_VALU")
+                rec["valu_busy"] = 4.0 * g("SQ_ACTIVE_INST_VALU") / (NSIMD * busy)
+                if g("SQ_THREAD_CYCLES_VALU"):
+                    rec["active_lanes"] = g("SQ_THREAD_CYCLES_VALU") / (64 * g("SQ_INSTS_VALU"))
+                if g("SQ_WAVE_CYCLES"):
+                    rec["waves_per_simd"] = 4.0 * g("SQ_WAVE_CYCLES") / (NSIMD * busy)
+            if g("TA_TA_BUSY_sum") and g("GRBM_GUI_ACTIVE"):
+                cyc = g("GRBM_GUI_ACTIVE") / NXCD
+                rec["ta_busy"] = g("TA_TA_BUSY_sum") / (NCU * cyc)
+                rec["td_busy"] = g("TD_TD_BUSY_sum") / (NCU * cyc)
+            if g("TCC_REQ_sum"):
+                rec["l2_hit"] = g("TCC_HIT_sum") / g("TCC_REQ_sum")
+            if not rec:
+                continue
+            if name in out and out[name].get("valu_insts", 0) >= rec.get("valu_insts", 0):
+                continue
+            out[name] = rec
+        print(json.dumps({pmc_json: out}, indent=1))
+        return
     if want_json:
         out = {}
         for k in kernels:
