@@ -261,6 +261,20 @@ int rtx_render_tiles_dev_enqueue(rtx_scene*, const rtx_camera*, const rtx_option
 int rtx_tiles_assemble_dev(const void* parts, int32_t nparts, uint64_t part_stride_pixels, rtx_rect rect,
                            int32_t tile_size, int32_t words_per_pixel, void* out, void* stream);
 
+/* Several GPUs in one process: Flyscene::raytraceScene's thread decomposition (src/flyscene.cpp:417-430,460:
+ * 16 threads striding the rows of one frame) as nscenes parts of the tile grid, part i rendered by scenes[i]
+ * on the device it was committed on -- all parts at once -- then copied to scenes[0]'s device (peer copies over
+ * xGMI) and put back into row-major order there.  Every entry of `scenes` is a handle of its own holding the same
+ * scene (rtx_scene_clone copies a scene's host description and its built BVH for the next device; two handles
+ * may share a device).  Outputs as rtx_render: row-major [y - y0][x - x0], any may be NULL; host pointers for
+ * rtx_render_multi, device pointers on scenes[0]'s device for rtx_render_multi_dev.  The frame is bit-identical
+ * to rtx_render's on one scene.  Ray counts and times stay per scene (rtx_get_stats of each handle). */
+int rtx_scene_clone(const rtx_scene* src, rtx_scene** out);
+int rtx_render_multi(rtx_scene* const* scenes, int32_t nscenes, const rtx_camera*, const rtx_options*, rtx_rect rect,
+                     int32_t tile_size, float* rgb, float* t, int32_t* face_id);
+int rtx_render_multi_dev(rtx_scene* const* scenes, int32_t nscenes, const rtx_camera*, const rtx_options*, rtx_rect rect,
+                         int32_t tile_size, float* rgb, float* t, int32_t* face_id);
+
 int rtx_get_stats(const rtx_scene*, rtx_stats*);
 
 #ifdef __cplusplus

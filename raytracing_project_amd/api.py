@@ -52,7 +52,8 @@ SYMBOLS = ["rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_
            "rtx_trace_visible", "rtx_render", "rtx_render_dev", "rtx_render_dev_enqueue", "rtx_render_finish", "rtx_tiles_count", "rtx_render_tiles_dev", "rtx_render_tiles_dev_enqueue", "rtx_tiles_assemble_dev",
            "rtx_get_stats", "rtx_scene_build_reference_leafboxes", "rtx_scene_set_leafboxes",
            "rtx_scene_get_leafboxes", "rtx_intersect_box", "rtx_trace_shade", "rtx_camera_points", "rtx_scene_set_flags",
-           "rtx_scene_get_packed_bvh", "rtx_debug_hit", "rtx_trace_closest_noalloc"]
+           "rtx_scene_get_packed_bvh", "rtx_debug_hit", "rtx_trace_closest_noalloc", "rtx_scene_clone", "rtx_render_multi",
+           "rtx_render_multi_dev"]
 
 NOALLOC_MAX_RAYS = 65536
 FLAG_NO_ROOT_GATE, FLAG_SCHED_REFILL, FLAG_SCHED_GROUPS, FLAG_SCHED_SPLIT = 1, 2, 4, 8
@@ -102,6 +103,10 @@ def lib():
         L.rtx_scene_get_bvh.argtypes = [C.c_void_p, _u, _u]
         L.rtx_trace_closest.argtypes = [C.c_void_p, _f, _f, C.c_uint32, _f, _i, _f, _f, _i]
         L.rtx_trace_closest_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.rtx_scene_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.rtx_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(Camera), C.POINTER(Options), Rect, C.c_int32, _f, _f, _i]
+        L.rtx_render_multi_dev.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(Camera), C.POINTER(Options), Rect, C.c_int32,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]
         L.rtx_trace_closest_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.rtx_trace_visible.argtypes = [C.c_void_p, _f, _f, C.c_uint32, C.POINTER(C.c_uint8), _i]
         L.rtx_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Options), Rect, _f, _f, _i]
@@ -178,6 +183,14 @@ class Scene:
         _check(L.rtx_scene_create(fp(self.verts), len(self.verts), self.idx.ctypes.data_as(_u),
                                   None if tm is None else tm.ctypes.data_as(_i), n, arr, len(mats), C.byref(h)))
         self.h = h
+
+    def clone(self):
+        """rtx_scene_clone: a second handle on the same scene (host data + built BVH), to commit on another device."""
+        h = C.c_void_p()
+        _check(lib().rtx_scene_clone(self.h, C.byref(h)))
+        other = Scene.__new__(Scene)
+        other.verts, other.idx, other.h = self.verts, self.idx, h
+        return other
 
     def close(self):
         if getattr(self, "h", None):
@@ -369,3 +382,24 @@ def tiles_assemble_dev(parts_ptr, nparts, part_stride_pixels, rect, tile_size, w
     x0, y0, x1, y1 = rect
     _check(lib().rtx_tiles_assemble_dev(parts_ptr, nparts, part_stride_pixels, Rect(x0, y0, x1, y1), tile_size,
                                         words_per_pixel, out_ptr, stream))
+
+
+def render_multi(scenes, cam, opts, rect, tile_size=32, want_rgb=True, want_hits=True):
+    """rtx_render_multi: part i of the tile grid on scenes[i]'s device, the frame assembled on scenes[0]'s; host arrays back."""
+    x0, y0, x1, y1 = rect
+    W, H = x1 - x0, y1 - y0
+    rgb = np.zeros((H, W, 3), np.float32) if want_rgb else None
+    t = np.zeros((H, W), np.float32) if want_hits else None
+    face = np.zeros((H, W), np.int32) if want_hits else None
+    hs = (C.c_void_p * len(scenes))(*[s.h for s in scenes])
+    _check(lib().rtx_render_multi(hs, len(scenes), C.byref(cam), C.byref(opts), Rect(x0, y0, x1, y1), tile_size,
+                                  fp(rgb) if want_rgb else None, fp(t) if want_hits else None,
+                                  face.ctypes.data_as(_i) if want_hits else None))
+    return rgb, t, face
+
+
+def render_multi_dev(scenes, cam, opts, rect, tile_size, rgb_ptr, t_ptr, face_ptr):
+    x0, y0, x1, y1 = rect
+    hs = (C.c_void_p * len(scenes))(*[s.h for s in scenes])
+    _check(lib().rtx_render_multi_dev(hs, len(scenes), C.byref(cam), C.byref(opts), Rect(x0, y0, x1, y1), tile_size,
+                                      rgb_ptr, t_ptr, face_ptr))

@@ -112,6 +112,8 @@ struct rtx_scene {
   };
   Slot slots[kSlots];
   DevBuf w_io[6];                      // staging of the host-pointer entry points (synchronous: never in use by a call in flight)
+  DevBuf m_part[3];                    // rtx_render_multi: this scene's compact tile buffers (rgb, t, face id) on its device
+  DevBuf m_gather[3];                  // ... and, on the first scene, the parts of all scenes one after the other
   // Per-call bookkeeping.  Two of them, so that a render call can be enqueued while the one before is
   // still running (rtx_render_dev_enqueue / rtx_render_finish); every other entry point begins and
   // finishes its call in one go.
@@ -190,6 +192,8 @@ static void release_device(rtx_scene* s) {
   }
   for (DevBuf* b : bufs) b->release();
   for (DevBuf& b : s->w_io) b.release();
+  for (DevBuf& b : s->m_part) b.release();
+  for (DevBuf& b : s->m_gather) b.release();
   for (rtx_scene::Slot& w : s->slots) {
     w.for_each_buf([](DevBuf& b) { b.release(); });
     w.cam_tab_ok = false;
@@ -1412,6 +1416,104 @@ extern "C" int rtx_render(rtx_scene* s, const rtx_camera* cam, const rtx_options
   if (t) HIP_TRY(hipMemcpy(t, s->w_io[1].p, npix * 4, hipMemcpyDeviceToHost));
   if (face) HIP_TRY(hipMemcpy(face, s->w_io[2].p, npix * 4, hipMemcpyDeviceToHost));
   return RTX_OK;
+}
+
+// ------------------------------------------------------------------ several GPUs, one process
+// A copy of a scene's host description and host-built acceleration data (no device state): what a caller commits
+// on another device without flattening the mesh and building the BVH again.
+extern "C" int rtx_scene_clone(const rtx_scene* src, rtx_scene** out) {
+  if (!src || !out) return fail(RTX_EINVAL, "null argument");
+  rtx_scene* s = new rtx_scene();
+  s->verts = src->verts; s->idx = src->idx; s->tri_mat = src->tri_mat; s->mats = src->mats;
+  s->spheres = src->spheres; s->sph_mat = src->sph_mat; s->lights = src->lights; s->slights = src->slights;
+  s->leaf_lo = src->leaf_lo; s->leaf_hi = src->leaf_hi; s->leaf_start = src->leaf_start; s->leaf_count = src->leaf_count;
+  s->leaf_faces = src->leaf_faces; s->have_leaves = src->have_leaves; s->flags = src->flags;
+  s->built = src->built; s->h_tri_leaf = src->h_tri_leaf; s->h_face_nm = src->h_face_nm; s->h_tri_face = src->h_tri_face;
+  std::memcpy(s->root_lo, src->root_lo, sizeof s->root_lo); std::memcpy(s->root_hi, src->root_hi, sizeof s->root_hi);
+  s->nwild = src->nwild; s->bvh = src->bvh; s->info = src->info;
+  *out = s;
+  return RTX_OK;
+}
+
+// Flyscene::raytraceScene's decomposition (src/flyscene.cpp:417-430,460: rows strided over 16 threads) over the
+// GPUs of one process: scene i renders part i of nscenes of the tile grid on its own device, all at once (each
+// scene has its own streams); the compact parts are copied to the first scene's device (peer copies over xGMI;
+// a plain device copy where two scenes share a device) and put back into row-major order there.
+static int render_multi(rtx_scene* const* scenes, int32_t n, const rtx_camera* cam, const rtx_options* opt, rtx_rect rect,
+                        int32_t tile_size, float* rgb, float* t, int32_t* face, bool host_out) {
+  if (!scenes || n < 1) return fail(RTX_EINVAL, "need at least one scene");
+  if (n > 64) return fail(RTX_ELIMIT, "at most 64 scenes");
+  for (int i = 0; i < n; ++i) {
+    if (int rc = check_ready(scenes[i])) return rc;
+    for (int j = 0; j < i; ++j) if (scenes[j] == scenes[i]) return fail(RTX_EINVAL, "scene %d is scene %d: every part needs a scene handle of its own (rtx_scene_clone)", i, j);
+  }
+  const int kmax = rtx_tiles_count(rect, tile_size, 0, n);
+  if (kmax < 0) return kmax;
+  const uint64_t stride = (uint64_t)kmax * (uint64_t)tile_size * (uint64_t)tile_size;      // pixels per part
+  if (stride >= (1ull << 31)) return fail(RTX_ELIMIT, "too many pixels in a part");
+  void* outs[3] = {rgb, t, face};
+  const int words[3] = {3, 1, 1};
+  rtx_scene* s0 = scenes[0];
+  const size_t npix = (size_t)(rect.x1 - rect.x0) * (size_t)(rect.y1 - rect.y0);
+  // buffers: part i of every wanted output on scene i's device; all parts on the first scene's device
+  HIP_TRY(hipSetDevice(s0->device));
+  for (int c = 0; c < 3; ++c) {
+    if (!outs[c]) continue;
+    if (int rc = s0->m_gather[c].ensure((size_t)n * stride * words[c] * 4)) return rc;
+    if (host_out) if (int rc = s0->w_io[c].ensure(npix * words[c] * 4)) return rc;
+  }
+  for (int i = 1; i < n; ++i) {
+    HIP_TRY(hipSetDevice(scenes[i]->device));
+    for (int c = 0; c < 3; ++c) if (outs[c]) if (int rc = scenes[i]->m_part[c].ensure(stride * words[c] * 4)) return rc;
+  }
+  auto part_ptr = [&](int i, int c) -> char* {      // scene 0 (and any scene on its device) renders straight into its slot of the gather buffer
+    if (!outs[c]) return nullptr;
+    if (scenes[i]->device == s0->device) return s0->m_gather[c].as<char>() + (size_t)i * stride * words[c] * 4;
+    return scenes[i]->m_part[c].as<char>();
+  };
+  // every part at once: the calls only queue work
+  int first_err = RTX_OK;
+  int queued = 0;
+  for (int i = 0; i < n && first_err == RTX_OK; ++i) {
+    first_err = render_tiles_impl(scenes[i], cam, opt, rect, tile_size, i, n, (float*)part_ptr(i, 0), (float*)part_ptr(i, 1),
+                                  (int32_t*)part_ptr(i, 2), false);
+    if (first_err == RTX_OK) ++queued;
+  }
+  std::string err = first_err ? g_err : std::string();
+  for (int i = 0; i < queued; ++i) {                   // (also after an error: nothing stays in flight)
+    const int rc = rtx_render_finish(scenes[i], nullptr);
+    if (rc && !first_err) { first_err = rc; err = g_err; }
+  }
+  if (first_err) { g_err = err; return first_err; }
+  HIP_TRY(hipSetDevice(s0->device));
+  hipStream_t st = ws(s0).stream;
+  for (int i = 1; i < n; ++i) {
+    if (scenes[i]->device == s0->device) continue;
+    for (int c = 0; c < 3; ++c) {
+      if (!outs[c]) continue;
+      const int nt = rtx_tiles_count(rect, tile_size, i, n);
+      const size_t bytes = (size_t)nt * tile_size * tile_size * words[c] * 4;
+      if (bytes) HIP_TRY(hipMemcpyPeerAsync(s0->m_gather[c].as<char>() + (size_t)i * stride * words[c] * 4, s0->device, scenes[i]->m_part[c].p,
+                                            scenes[i]->device, bytes, st));
+    }
+  }
+  for (int c = 0; c < 3; ++c) {
+    if (!outs[c]) continue;
+    void* dst = host_out ? s0->w_io[c].p : outs[c];
+    if (int rc = rtx_tiles_assemble_dev(s0->m_gather[c].p, n, stride, rect, tile_size, words[c], dst, (void*)st)) return rc;
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  if (host_out)
+    for (int c = 0; c < 3; ++c) if (outs[c]) HIP_TRY(hipMemcpy(outs[c], s0->w_io[c].p, npix * words[c] * 4, hipMemcpyDeviceToHost));
+  return RTX_OK;
+}
+extern "C" int rtx_render_multi(rtx_scene* const* scenes, int32_t nscenes, const rtx_camera* cam, const rtx_options* opt, rtx_rect rect,
+                                int32_t tile_size, float* rgb, float* t, int32_t* face) {
+  return render_multi(scenes, nscenes, cam, opt, rect, tile_size, rgb, t, face, true);
+}
+extern "C" int rtx_render_multi_dev(rtx_scene* const* scenes, int32_t nscenes, const rtx_camera* cam, const rtx_options* opt, rtx_rect rect,
+                                    int32_t tile_size, float* rgb, float* t, int32_t* face) {
+  return render_multi(scenes, nscenes, cam, opt, rect, tile_size, rgb, t, face, false);
 }
 
 // ------------------------------------------------------------------ the entry point that allocates nothing

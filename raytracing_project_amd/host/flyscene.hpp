@@ -306,8 +306,12 @@ inline bool loadPlyFile(MeshData& mesh, const std::string& filename) {
   }
   return true;
 }
-inline void writePPMImage(const std::string& filename, const std::vector<std::vector<Vector3f>>& data) {
-  int width = (int)data[0].size(), height = (int)data.size();
+// tucano/utils/ppmIO.hpp:130-151 with the frame's size given: data is indexed [x][y], width x height
+// values are written row by row.  Byte-identical to the reference's writer wherever that one is defined.
+inline void writePPMImageXY(const std::string& filename, const std::vector<std::vector<Vector3f>>& data, int width, int height) {
+  if ((int)data.size() < width) throw RtxError(RTX_EINVAL, "writePPMImage: the frame buffer has fewer than `width` columns");
+  for (int i = 0; i < width; ++i)
+    if ((int)data[i].size() < height) throw RtxError(RTX_EINVAL, "writePPMImage: a frame buffer column has fewer than `height` entries");
   std::ofstream out(filename.c_str());
   out << "P3\n" << width << " " << height << "\n255\n";
   for (int j = 0; j < height; ++j) {
@@ -316,6 +320,16 @@ inline void writePPMImage(const std::string& filename, const std::vector<std::ve
           << std::min(255, (int)(255 * data[i][j][2])) << " ";
     out << "\n";
   }
+}
+// The reference's signature: width = data[0].size(), height = data.size(), and data[i][j] with i < width, j < height
+// -- inside the buffer only when it is square.  Anything else is refused instead of read out of bounds.
+inline void writePPMImage(const std::string& filename, const std::vector<std::vector<Vector3f>>& data) {
+  if (data.empty()) throw RtxError(RTX_EINVAL, "writePPMImage: empty frame buffer");
+  const int width = (int)data[0].size(), height = (int)data.size();
+  if (width != height)
+    throw RtxError(RTX_EINVAL, "writePPMImage(data): the reference indexes data[x][y] in a [height][width] buffer, which is only inside it for "
+                               "square frames; use writePPMImageXY(filename, data, width, height) with a buffer indexable [x][y]");
+  writePPMImageXY(filename, data, width, height);
 }
 
 // ---- Flyscene (src/flyscene.hpp:30-221), ray-tracing half
@@ -328,7 +342,7 @@ class Flyscene {
   Box root_box;                                                  // src/flyscene.hpp:219
 
   Flyscene() {}
-  ~Flyscene() { if (scene) rtx_scene_destroy(scene); }
+  ~Flyscene() { drop_replicas(); if (scene) rtx_scene_destroy(scene); }
   Flyscene(const Flyscene&) = delete;
   Flyscene& operator=(const Flyscene&) = delete;
 
@@ -349,34 +363,58 @@ class Flyscene {
   void addSphericalLight() { sphericalLights.push_back({getCenter(), 0.01f}); dirty = true; }   // :62
   int getNumberOfFaces() const { return (int)mesh.tri_mat.size(); }
 
-  // src/flyscene.cpp:395-439
+  // src/flyscene.cpp:395-439.  The frame buffer is indexed [x][y] as the reference does (:465); the
+  // reference allocates it [height][width], which holds that indexing only for square frames and is out of bounds
+  // otherwise.  Here it is allocated [width][height]: the same object for square frames (result.ppm byte-identical),
+  // and a defined result for every other size.
   void raytraceScene(int width = 0, int height = 0) {
     std::cout << "ray tracing ..." << std::endl;
     auto t0 = std::chrono::steady_clock::now();
     Vector2i image_size(width, height);
     if (width == 0 || height == 0) image_size = flycamera.getViewportSize();
-    std::vector<std::vector<Vector3f>> pixel_data(image_size[1]);
-    for (int i = 0; i < image_size[1]; ++i) pixel_data[i].resize(image_size[0]);
+    std::vector<std::vector<Vector3f>> pixel_data(image_size[0]);
+    for (int i = 0; i < image_size[0]; ++i) pixel_data[i].resize(image_size[1]);
     Vector3f origin = getCenter();
     updating_pixels(pixel_data, origin, image_size, 1, 0);       // one GPU frame instead of 16 racing threads
-    writePPMImage("result.ppm", pixel_data);
+    writePPMImageXY("result.ppm", pixel_data, image_size[0], image_size[1]);
     auto ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     std::cout << "Time elapsed: " << (long)ms << " ms" << std::endl << "ray tracing done! " << std::endl;
   }
 
+  // How many scene handles render a frame (rtx_render_multi: part i of the tile grid on handle i, all at once):
+  // 0 = one per visible GPU, the multi-GPU form of the reference's 16 threads (src/flyscene.cpp:417-430); 1 = a
+  // single rtx_render.  Handles beyond the number of GPUs share devices (device = index modulo GPUs).
+  int render_parts = 0;
+  int tile_size = 32;
+
   // src/flyscene.cpp:441-468.  Rows thread_id, thread_id + number_threads, ... of the frame are
-  // written to pixel_data[i][j] (the reference's [x][y] indexing).  The spheres are
+  // written to pixel_data[i][j] (the reference's [x][y] indexing): the buffer must be
+  // indexable that way -- at least image_size[0] columns of at least image_size[1] entries --
+  // or the call is refused (the reference writes out of bounds instead).  The spheres are
   // added once, not once per thread.
   void updating_pixels(std::vector<std::vector<Vector3f>>& pixel_data, Vector3f& /*origin*/, Vector2i& image_size,
                        int number_threads, int thread_id) {
+    const int W = image_size[0], H = image_size[1];
+    if (W <= 0 || H <= 0 || number_threads <= 0 || thread_id < 0) throw RtxError(RTX_EINVAL, "updating_pixels: bad image size or thread index");
+    if ((int)pixel_data.size() < W) throw RtxError(RTX_EINVAL, "updating_pixels: pixel_data[x][y] needs image_size[0] columns (SURVEY F8)");
+    for (int i = 0; i < W; ++i)
+      if ((int)pixel_data[i].size() < H) throw RtxError(RTX_EINVAL, "updating_pixels: pixel_data[x][y] needs image_size[1] entries per column (SURVEY F8)");
     if (!spheres_added) add_reference_spheres();
     sync();
-    const int W = image_size[0], H = image_size[1];
     if (frame_w != W || frame_h != H || frame_dirty) {
       frame.resize((size_t)W * H * 3);
       rtx_camera cam = flycamera.raw();
       rtx_rect r{0, 0, W, H};
-      rtx_check(rtx_render(scene, &cam, &options, r, frame.data(), nullptr, nullptr));
+      int ndev = rtx_device_count();
+      int parts = render_parts > 0 ? render_parts : ndev;
+      if (parts > 1 && ndev >= 1) {
+        ensure_replicas(parts, ndev);
+        std::vector<rtx_scene*> hs(1, scene);
+        hs.insert(hs.end(), replicas.begin(), replicas.end());
+        rtx_check(rtx_render_multi(hs.data(), parts, &cam, &options, r, tile_size, frame.data(), nullptr, nullptr));
+      } else {
+        rtx_check(rtx_render(scene, &cam, &options, r, frame.data(), nullptr, nullptr));
+      }
       frame_w = W; frame_h = H; frame_dirty = false;
     }
     for (int j = thread_id; j < H; j += number_threads)
@@ -518,6 +556,18 @@ class Flyscene {
   int frame_w = 0, frame_h = 0;
   rtx_stats stats{};
 
+  std::vector<rtx_scene*> replicas;        // handles 1 .. parts-1 of rtx_render_multi (clones of `scene`, committed on their devices)
+  void drop_replicas() { for (rtx_scene* r : replicas) rtx_scene_destroy(r); replicas.clear(); }
+  void ensure_replicas(int parts, int ndev) {
+    if ((int)replicas.size() == parts - 1) return;
+    drop_replicas();
+    for (int i = 1; i < parts; ++i) {
+      rtx_scene* r = nullptr;
+      rtx_check(rtx_scene_clone(scene, &r));
+      replicas.push_back(r);
+      rtx_check(rtx_scene_commit(r, (device + i) % ndev));
+    }
+  }
   Tucano::Face make_face(int f) {
     Tucano::Face face;
     for (int k = 0; k < 3; ++k) face.vertex_ids.push_back(mesh.idx[3 * (size_t)f + k]);
@@ -525,6 +575,7 @@ class Flyscene {
     return face;
   }
   void rebuild() {
+    drop_replicas();
     if (scene) { rtx_scene_destroy(scene); scene = nullptr; }
     std::vector<rtx_material> raw;
     for (size_t i = 0; i < mesh_materials; ++i) raw.push_back(materials[i].raw());
@@ -556,6 +607,7 @@ class Flyscene {
   // push lights / spheres / appended materials and (re)commit when something changed
   void sync() {
     if (!dirty) return;
+    drop_replicas();                       // clones of the scene as it was
     rtx_scene_info info{};
     std::vector<float> L, SL, S;
     std::vector<int32_t> SM;

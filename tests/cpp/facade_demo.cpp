@@ -52,10 +52,31 @@ int main(int argc, char** argv) {
         std::printf("lseg %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", sgm.origin[0], sgm.origin[1], sgm.origin[2], sgm.dir[0], sgm.dir[1],
                     sgm.dir[2], sgm.length);
     }
+    fs.render_parts = 1;
     fs.raytraceScene(W, W);       // adds the 13 spheres, renders, writes result.ppm
     const rtx_stats& st = fs.lastStats();
     std::printf("frame rays %llu %llu %llu %llu %llu\n", (unsigned long long)st.rays_primary, (unsigned long long)st.rays_shadow,
                 (unsigned long long)st.rays_reflection, (unsigned long long)st.rays_refraction, (unsigned long long)st.rays_gi);
+    std::rename("result.ppm", "result_square.ppm");
+    // a frame that is not square (out of bounds in the reference), its viewport set like initialize does
+    const int W2 = W + W / 2, H2 = W - W / 4;
+    fs.getCamera()->setPerspectiveMatrix(60.0f, W2 / (float)H2, 0.1f, 100.0f);
+    fs.getCamera()->setViewport(Vector2f((float)W2, (float)H2));
+    fs.markCameraChanged();
+    fs.raytraceScene(W2, H2);
+    std::rename("result.ppm", "result_wide.ppm");
+    // the same frame as three parts of the tile grid on three scene handles (rtx_render_multi; with one GPU they share it)
+    fs.render_parts = 3; fs.tile_size = 16;
+    fs.markCameraChanged();
+    fs.raytraceScene(W2, H2);
+    std::rename("result.ppm", "result_wide_3parts.ppm");
+    // a caller's own buffer in the reference's [height][width] shape is refused for a non-square frame, not overrun
+    {
+      std::vector<std::vector<Vector3f>> bad((size_t)H2, std::vector<Vector3f>((size_t)W2));
+      Vector3f origin = fs.getCenter(); Vector2i size(W2, H2);
+      try { fs.updating_pixels(bad, origin, size, 1, 0); std::printf("nonsquare accepted\n"); }
+      catch (const RtxError&) { std::printf("nonsquare refused\n"); }
+    }
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());
     return 1;

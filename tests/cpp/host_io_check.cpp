@@ -55,7 +55,14 @@ int main(int argc, char** argv) {
         const float* p = &px[((size_t)j * wh[0] + i) * 3];
         data[i][j] = Vector3f(p[0], p[1], p[2]);
       }
-    writePPMImage(argv[3], data);
+    // square frames through the reference's signature; other sizes through the one that is told the size (the
+    // reference's writer reads outside a non-square buffer, SURVEY F8, and the facade refuses to)
+    try {
+      if (wh[0] == wh[1]) writePPMImage(argv[3], data); else writePPMImageXY(argv[3], data, wh[0], wh[1]);
+      if (wh[0] != wh[1]) {
+        try { writePPMImage(argv[3], data); return 3; } catch (const RtxError&) {}     // must refuse
+      }
+    } catch (const RtxError& e) { std::fprintf(stderr, "%s\n", e.what()); return 1; }
     return 0;
   }
   return 64;

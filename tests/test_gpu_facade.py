@@ -115,10 +115,24 @@ def test_facade_matches_oracle(tmp_path, oa):
     o.set_spheres(cr, ids)
     want, _, _ = o.render(oa.make_camera(scenes.default_view(), W, W), (0, 0, W, W), threads=8, want_hits=False)
     assert oa.lib().ora_ppm_write(str(tmp_path / "want.ppm").encode(), oa.fp(want), W, W, 0) == 0
-    got_txt = open(tmp_path / "result.ppm").read().split()
+    got_txt = open(tmp_path / "result_square.ppm").read().split()
     want_txt = open(tmp_path / "want.ppm").read().split()
     assert got_txt[:4] == want_txt[:4] == ["P3", str(W), str(W), "255"]
     g = np.array(got_txt[4:], np.int64)
     w = np.array(want_txt[4:], np.int64)
     assert g.shape == w.shape and np.abs(g - w).max() <= 1      # 1e-4 relative on [0,1] floats can move a byte by one
     assert (g != w).mean() < 0.01
+    # a frame that is not square (the reference writes out of bounds there; the facade's [x][y] buffer has the
+    # frame's own shape), rendered once by one scene handle and once as three parts of the tile grid on three handles
+    # (rtx_render_multi through Flyscene::raytraceScene): the same file both times, equal to the oracle's frame
+    W2, H2 = W + W // 2, W - W // 4
+    want2, _, _ = o.render(oa.make_camera(scenes.default_view(), W2, H2), (0, 0, W2, H2), threads=8, want_hits=False)
+    assert oa.lib().ora_ppm_write(str(tmp_path / "want_wide.ppm").encode(), oa.fp(want2), W2, H2, 0) == 0
+    wide = open(tmp_path / "result_wide.ppm").read()
+    assert wide == open(tmp_path / "result_wide_3parts.ppm").read()
+    got_txt, want_txt = wide.split(), open(tmp_path / "want_wide.ppm").read().split()
+    assert got_txt[:4] == want_txt[:4] == ["P3", str(W2), str(H2), "255"]
+    g = np.array(got_txt[4:], np.int64)
+    w = np.array(want_txt[4:], np.int64)
+    assert g.shape == w.shape and np.abs(g - w).max() <= 1 and (g != w).mean() < 0.01
+    assert ["nonsquare", "refused"] in lines

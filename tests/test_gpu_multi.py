@@ -1,0 +1,94 @@
+"""rtx_render_multi / rtx_scene_clone: several scene handles render the parts of one frame at once and the first
+one's device assembles it (the native, one-process form of the multi-GPU tile partition; src/flyscene.cpp:417-430
+is the reference's only parallel decomposition).  On the one-GPU test box every handle is committed on device 0:
+the control flow, the part buffers, the copies into the gather buffer and the reassembly are the same, the peer
+copy degenerates to a device copy.  The frame must be bit-identical to rtx_render's."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal, load_scene_fixture, rtx_materials
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    from raytracing_project_amd import api
+    assert api.lib().rtx_device_count() >= 1, "no GPU visible: the HIP path cannot run (there is no fallback)"
+    return api
+
+
+def test_render_multi_equals_single_scene_frame(api):
+    import torch
+    fx = load_scene_fixture("spheres")
+    s = api.Scene(fx["verts"], fx["idx"], fx["tri_mat"], rtx_materials(fx["mats"]))
+    s.set_lights([[-1.0, 1.0, 1.0], [1.0, 2.0, 0.5]])
+    s.commit(0)
+    ndev = api.lib().rtx_device_count()
+    W, H = 150, 83
+    cam = api.make_camera(fx["view_oblique"], W, H)
+    opts = api.Options(2, 1, 0, 0, 1, 0)
+    full = s.render(cam, opts, (0, 0, W, H))
+    clones = []
+    for i in range(1, 5):
+        c = s.clone()
+        assert c.info().ntris == s.info().ntris and c.info().nnodes == s.info().nnodes     # the built BVH travels with the clone
+        c.commit(i % ndev)
+        clones.append(c)
+    for n in (1, 2, 3, 5):
+        for ts in (16, 32):
+            rgb, t, face = api.render_multi([s] + clones[:n - 1], cam, opts, (0, 0, W, H), ts)
+            assert np.array_equal(face, full[2]), (n, ts)
+            assert_bits_equal(t, full[1], "t (%d parts, tile %d)" % (n, ts))
+            assert_bits_equal(rgb, full[0], "rgb (%d parts, tile %d)" % (n, ts))
+    # sub-rectangle, RGB only, device-pointer form
+    rect = (16, 9, 131, 70)
+    x0, y0, x1, y1 = rect
+    out = torch.zeros((y1 - y0, x1 - x0, 3), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    api.render_multi_dev([s] + clones[:2], cam, opts, rect, 32, out.data_ptr(), None, None)
+    assert_bits_equal(out.cpu().numpy(), full[0][y0:y1, x0:x1], "rgb of a sub-rectangle, 3 parts, device pointers")
+    # more parts than tiles: the handles without a tile render nothing
+    small = s.render(api.make_camera(fx["view_oblique"], 40, 20), opts, (0, 0, 40, 20))
+    rgb, t, face = api.render_multi([s] + clones, api.make_camera(fx["view_oblique"], 40, 20), opts, (0, 0, 40, 20), 32)
+    assert np.array_equal(face, small[2]) and np.array_equal(rgb.view(np.uint32), small[0].view(np.uint32))
+    # every part needs a handle of its own; a clone that was never committed is refused
+    with pytest.raises(api.RtxError, match="handle of its own"):
+        api.render_multi([s, s], cam, opts, (0, 0, W, H), 32)
+    fresh = s.clone()
+    with pytest.raises(api.RtxError, match="not committed"):
+        api.render_multi([s, fresh], cam, opts, (0, 0, W, H), 32)
+    # the single-scene entry points still work on every handle afterwards, and give the same frame
+    again = clones[1].render(cam, opts, (0, 0, W, H))
+    assert_bits_equal(again[0], full[0], "rgb of a clone on its own")
+    fresh.close()
+    for c in clones:
+        c.close()
+    s.close()
+
+
+def test_render_multi_full_size_soup(api):
+    """BASELINE config 4's frame (1M-triangle soup, 3840x2160, primary + shadow) as 4 parts on 4 handles."""
+    from raytracing_project_amd import scenes
+    verts, idx = scenes.soup(1000000, seed=0x5EED0001, h=0.02)
+    mat = api.make_material(ka=(0, 0, 0), kd=(.7, .7, .7), ks=(.2, .2, .2), ns=10, d=1.0)
+    s = api.Scene(verts, idx, np.zeros(len(idx), np.int32), [mat])
+    s.set_lights([[-2.0, 2.0, 2.0]])
+    s.commit(0)
+    ndev = api.lib().rtx_device_count()
+    W, H = 3840, 2160
+    cam = api.make_camera(scenes.look_at_view((0, 0, 3), (0, 0, 0)), W, H)
+    opts = api.Options(0, 1, 0, 0, 1, 1)
+    full = s.render(cam, opts, (0, 0, W, H))
+    clones = [s.clone() for _ in range(3)]
+    for i, c in enumerate(clones):
+        c.commit((i + 1) % ndev)
+    rgb, t, face = api.render_multi([s] + clones, cam, opts, (0, 0, W, H), 32)
+    prim = sum(h.stats().rays_primary for h in [s] + clones)
+    assert prim == W * H
+    assert np.array_equal(face, full[2])
+    assert_bits_equal(t, full[1], "t")
+    assert_bits_equal(rgb, full[0], "rgb")
+    for c in clones:
+        c.close()
+    s.close()

@@ -152,3 +152,13 @@ def test_ppm_writer_is_byte_identical_to_the_oracle_writer(tool, oa, tmp_path):
         assert rc == 0, err
         assert oa.lib().ora_ppm_write(str(tmp_path / "e.ppm").encode(), fp(rgb), n, n, 0) == 0
         assert open(tmp_path / "o.ppm", "rb").read() == open(tmp_path / "e.ppm", "rb").read()
+    # non-square frames (no defined behaviour in the reference): the facade's [x][y] buffer of the frame's
+    # own size gives the ordinary row-major file, and the reference-signature writer refuses instead of reading outside
+    for w, h in ((5, 3), (3, 8), (64, 17)):
+        rgb = rng.random((h, w, 3)).astype(np.float32)
+        with open(tmp_path / "i.bin", "wb") as f:
+            f.write(struct.pack("<2i", w, h)); f.write(rgb.tobytes())
+        rc, err = run(tool, "ppm", tmp_path / "i.bin", tmp_path / "o.ppm")
+        assert rc == 0, err
+        assert oa.lib().ora_ppm_write(str(tmp_path / "e.ppm").encode(), fp(rgb), w, h, 0) == 0
+        assert open(tmp_path / "o.ppm", "rb").read() == open(tmp_path / "e.ppm", "rb").read()
