@@ -105,9 +105,10 @@ struct rtx_scene {
     DevBuf w_stack_ovf;                // global overflow columns of the per-lane traversal stacks
     DevBuf w_stack_ovf2;               // ... of the launches on stream2 (they run beside launches on `stream`)
     DevBuf w_rays[2], w_hits[3], w_parents, w_shadow_rays, w_shadow_hits, w_gi_rays, w_gi_hits, w_counters;
+    DevBuf w_acc, w_acc_flag;          // fixed-point pixel sums of ray-tree calls (reflection + refraction)
     template <class F> void for_each_buf(F f) {
       f(w_cam_tab); f(w_stack_ovf); f(w_stack_ovf2); f(w_rays[0]); f(w_rays[1]); f(w_hits[0]); f(w_hits[1]); f(w_hits[2]);
-      f(w_parents); f(w_shadow_rays); f(w_shadow_hits); f(w_gi_rays); f(w_gi_hits); f(w_counters);
+      f(w_parents); f(w_shadow_rays); f(w_shadow_hits); f(w_gi_rays); f(w_gi_hits); f(w_counters); f(w_acc); f(w_acc_flag);
     }
   };
   Slot slots[kSlots];
@@ -1155,6 +1156,10 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
       if (int rc = ws(s).w_gi_rays.ensure((size_t)max_nodes * G * 32)) return rc;
       if (int rc = ws(s).w_gi_hits.ensure((size_t)max_nodes * G * 8)) return rc;
     }
+    if (tree) {
+      if (int rc = ws(s).w_acc.ensure((size_t)pr.n0 * 24)) return rc;
+      if (int rc = ws(s).w_acc_flag.ensure((size_t)pr.n0 * 4)) return rc;
+    }
     if (max_gen > 0) {
       if (int rc = ws(s).w_rays[0].ensure((size_t)max_nodes * 32)) return rc;
       if (int rc = ws(s).w_rays[1].ensure((size_t)max_nodes * 32)) return rc;
@@ -1202,6 +1207,7 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
     A.gi_q = ws(s).w_gi_rays.as<float4>(); A.gi_hits = ws(s).w_gi_hits.as<uint2>();
     A.next_rays = ws(s).w_rays[nxt].as<float4>();
     A.counters = cnt + 4 * g;
+    A.acc = ws(s).w_acc.as<long long>(); A.acc_flag = ws(s).w_acc_flag.as<uint32_t>();
     A.gi_sin = sinf(th_gi); A.gi_cos = cosf(th_gi); A.sl_sin = sinf(th_sl); A.sl_cos = cosf(th_sl);
     hipLaunchKernelGGL(k_shade, dim3(grid_for(s, bound)), dim3(kBlock), 0, ws(s).stream, A);
     if (!shade) break;
@@ -1234,6 +1240,11 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
       span_end(s, true);
     }
     hipLaunchKernelGGL(k_resolve, dim3(grid_for(s, bound)), dim3(kBlock), 0, ws(s).stream, A);
+    if (tree && g == max_gen) {          // the last generation is in: fixed-point sums -> the caller's pixels
+      PipeArgs F = A;
+      F.from_camera = pr.camera ? 1 : 0;
+      hipLaunchKernelGGL(k_acc_to_rgb, dim3(grid_for(s, pr.n0)), dim3(kBlock), 0, ws(s).stream, F);
+    }
     if (g < max_gen) {
       bound = bound_next;
       if (side_done) {

@@ -789,11 +789,36 @@ struct PipeArgs {
   const uint2* gi_hits;  // {t bits (0 = nothing), material id}
   float4* next_rays;     // nodes of the next generation
   uint32_t* counters;    // [0] = #parents, [1] = #next nodes
+  long long* acc;        // atomic_accum: per pixel 3 x 40.24 fixed-point sums (integer addition is associative: the
+  uint32_t* acc_flag;    // frame does not depend on the order the nodes arrive in) + flags for non-finite terms
   float gi_sin, gi_cos;  // sinf/cosf of (float)(2*pi / gi_rays), evaluated on the host (glibc, like the reference)
   float sl_sin, sl_cos;  // same for the 4-point ring of spherical lights
 };
 
 struct RayRec { V3 o, d1; uint32_t pixel; float thr; bool inside; bool valid; };
+
+// Order-independent accumulation for ray trees (reflection AND refraction: several nodes of a generation share a
+// pixel and arrive in whatever order the queue compaction gave them).  A float atomic sum would depend on that
+// order ((p + a) + b != (p + b) + a in fp32); a 64-bit integer sum does not.  2^-40 resolution (1e-12, against an
+// RGB tolerance of 1e-4), range +-8e6.  Terms that are not finite (a material with a negative shininess can give
+// pow(0, Ns) = inf) set per-channel flags instead: 1 = +inf, 2 = -inf, 4 = NaN, three bits per channel.
+constexpr double kAccScale = 1099511627776.0;     // 2^40
+__device__ __forceinline__ long long acc_fixed(float x) { return __double2ll_rn((double)x * kAccScale); }
+__device__ __forceinline__ void acc_add(const PipeArgs& A, uint32_t pixel, int c, float x) {
+  if (x - x == 0.0f && fabsf(x) < 4.0e6f) {
+    atomicAdd((unsigned long long*)(A.acc + 3 * (size_t)pixel + c), (unsigned long long)acc_fixed(x));
+  } else {
+    const uint32_t bit = (x != x) ? 4u : (x > 0.0f ? 1u : 2u);     // (a finite term beyond the range counts as an infinity)
+    atomicOr(A.acc_flag + pixel, bit << (3 * c));
+  }
+}
+__device__ __forceinline__ float acc_value(long long v, uint32_t flags) {
+  if (flags & 4u) return __uint_as_float(0x7FC00000u);
+  if ((flags & 3u) == 3u) return __uint_as_float(0x7FC00000u);
+  if (flags & 1u) return INFINITY;
+  if (flags & 2u) return -INFINITY;
+  return (float)((double)v / kAccScale);
+}
 
 __device__ __forceinline__ RayRec load_node(const PipeArgs& A, uint32_t i) {
   RayRec r;
@@ -974,9 +999,16 @@ __global__ __launch_bounds__(kBlock) void k_shade(PipeArgs A) {
     if (live && sp.valid && A.first_gen) {
       // traceRay's miss colour at bounce 0 (src/flyscene.cpp:596-600); hit pixels start at 0 and
       // receive their nodes' colours from k_resolve
-      float* px = A.rgb + 3 * (size_t)r.pixel;
       const bool sky = !sp.hit && A.bounce == 0;
-      px[0] = sky ? (float)0.69019607843 : 0.0f; px[1] = sky ? 1.0f : 0.0f; px[2] = sky ? 1.0f : 0.0f;
+      const float c0 = sky ? (float)0.69019607843 : 0.0f, c1 = sky ? 1.0f : 0.0f;
+      if (A.atomic_accum) {
+        long long* ax = A.acc + 3 * (size_t)r.pixel;
+        ax[0] = acc_fixed(c0); ax[1] = acc_fixed(c1); ax[2] = acc_fixed(c1);
+        A.acc_flag[r.pixel] = 0u;
+      } else {
+        float* px = A.rgb + 3 * (size_t)r.pixel;
+        px[0] = c0; px[1] = c1; px[2] = c1;
+      }
     }
     const uint32_t off_par = wave_alloc_lds(sp.hit, &s_run[0]);
     const uint32_t off_r = wave_alloc_lds(sp.refl, &s_run[1]);
@@ -1124,8 +1156,17 @@ __global__ __launch_bounds__(kBlock) void k_resolve(PipeArgs A) {
     }
     float* px = A.rgb + 3 * (size_t)r.pixel;
     const V3 add = v3(r.thr * total.x, r.thr * total.y, r.thr * total.z);
-    if (A.atomic_accum) { atomicAdd(px, add.x); atomicAdd(px + 1, add.y); atomicAdd(px + 2, add.z); }
+    if (A.atomic_accum) { acc_add(A, r.pixel, 0, add.x); acc_add(A, r.pixel, 1, add.y); acc_add(A, r.pixel, 2, add.z); }
     else { px[0] += add.x; px[1] += add.y; px[2] += add.z; }
+  }
+}
+
+// The fixed-point sums of a ray-tree call -> the caller's float pixels (slots of partial edge tiles stay untouched).
+__global__ __launch_bounds__(kBlock) void k_acc_to_rgb(PipeArgs A) {
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < A.n0; i += gridDim.x * kBlock) {
+    if (A.from_camera) { int x, y; if (!slot_pixel(A.C, i, &x, &y)) continue; }
+    const uint32_t f = A.acc_flag[i];
+    for (int c = 0; c < 3; ++c) A.rgb[3 * (size_t)i + c] = acc_value(A.acc[3 * (size_t)i + c], (f >> (3 * c)) & 7u);
   }
 }
 
