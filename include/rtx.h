@@ -84,6 +84,8 @@ typedef struct {
   float build_ms;
   uint32_t nwild;     /* ill-conditioned triangles kept out of the BVH (tested by every ray) */
   uint32_t nslots;    /* non-empty node slots; nnodes counts all 32-byte slots (4 per group) */
+  uint32_t ntop_groups;   /* groups 0 .. ntop_groups-1 are the top three levels of the hierarchy, numbered breadth first
+                             (the group-by-group traversal kernels keep them in LDS); deeper groups follow depth first */
 } rtx_scene_info;
 
 const char* rtx_last_error(void);

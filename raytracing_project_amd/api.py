@@ -41,7 +41,7 @@ class SceneInfo(C.Structure):
     _fields_ = [("ntris", C.c_uint32), ("nverts", C.c_uint32), ("nnodes", C.c_uint32), ("nleaves", C.c_uint32),
                 ("max_depth", C.c_uint32), ("nspheres", C.c_uint32), ("nlights", C.c_uint32),
                 ("nmaterials", C.c_uint32), ("device_bytes", C.c_uint64), ("build_ms", C.c_float),
-                ("nwild", C.c_uint32), ("nslots", C.c_uint32)]
+                ("nwild", C.c_uint32), ("nslots", C.c_uint32), ("ntop_groups", C.c_uint32)]
 
 
 # every symbol include/rtx.h declares

@@ -230,17 +230,18 @@ void build_bvh(const float* tri_lo, const float* tri_hi, uint32_t ntris, int thr
 
 
 namespace {
-uint32_t collapse_node(const std::vector<BvhNode>& bin, uint32_t b, std::vector<BvhNode>& q, uint32_t depth, BvhBuildResult* out) {
+// Fills group g with the (up to 4) grandchildren of binary node b; returns how many slots are in use and, per slot,
+// the binary node it came from.
+int fill_group(const std::vector<BvhNode>& bin, uint32_t b, std::vector<BvhNode>& q, uint32_t g, uint32_t depth, BvhBuildResult* out,
+               uint32_t cand[4]) {
   // candidates: the two children of b, each replaced by its own children when internal
-  uint32_t cand[4]; int nc = 0;
+  int nc = 0;
   const uint32_t kids[2] = {bin[b].leftFirst, bin[b].leftFirst + 1};
   for (int k = 0; k < 2; ++k) {
     const BvhNode& c = bin[kids[k]];
     if (c.count == 0) { cand[nc++] = c.leftFirst; cand[nc++] = c.leftFirst + 1; }
     else cand[nc++] = kids[k];
   }
-  const uint32_t g = (uint32_t)(q.size() / 4);
-  q.resize(q.size() + 4);
   out->quad_depth = std::max(out->quad_depth, depth);
   for (int k = 0; k < 4; ++k) {
     BvhNode s;
@@ -253,6 +254,14 @@ uint32_t collapse_node(const std::vector<BvhNode>& bin, uint32_t b, std::vector<
     }
     q[4 * (size_t)g + k] = s;
   }
+  return nc;
+}
+// Depth first below the top levels: a subtree's groups stay together in memory.
+uint32_t collapse_node(const std::vector<BvhNode>& bin, uint32_t b, std::vector<BvhNode>& q, uint32_t depth, BvhBuildResult* out) {
+  uint32_t cand[4];
+  const uint32_t g = (uint32_t)(q.size() / 4);
+  q.resize(q.size() + 4);
+  const int nc = fill_group(bin, b, q, g, depth, out, cand);
   for (int k = 0; k < nc; ++k) {
     if (bin[cand[k]].count == 0) {
       const uint32_t child = collapse_node(bin, cand[k], q, depth + 1, out);
@@ -265,11 +274,50 @@ uint32_t collapse_node(const std::vector<BvhNode>& bin, uint32_t b, std::vector<
 
 void collapse_to_quads(BvhBuildResult* out) {
   out->quads.clear(); out->quad_depth = 0; out->quad_slots = 0;
+  for (uint32_t& t : out->top_groups) t = 0;
   const std::vector<BvhNode>& bin = out->nodes;
   const BvhNode& root = bin[0];
   if (root.count == 0 && bin.size() >= 3) {        // internal root
-    out->quads.reserve(bin.size() * 2);
-    collapse_node(bin, 0, out->quads, 1, out);
+    std::vector<BvhNode>& q = out->quads;
+    q.reserve(bin.size() * 2);
+    // The first kTopLevels levels breadth first, so that their groups are 0 .. top_groups[level]-1 (the kernels keep
+    // them in LDS); everything below depth first.
+    struct Item { uint32_t bin_node, group, depth; };
+    std::vector<Item> fifo;
+    q.resize(4);
+    fifo.push_back({0u, 0u, 1u});
+    for (size_t head = 0; head < fifo.size(); ++head) {
+      const Item it = fifo[head];
+      uint32_t cand[4];
+      const int nc = fill_group(bin, it.bin_node, q, it.group, it.depth, out, cand);
+      for (int k = 0; k < nc; ++k) {
+        if (bin[cand[k]].count != 0) continue;
+        if (it.depth < (uint32_t)kTopLevels) {
+          const uint32_t child = (uint32_t)(q.size() / 4);
+          q.resize(q.size() + 4);
+          q[4 * (size_t)it.group + k].leftFirst = child;
+          fifo.push_back({cand[k], child, it.depth + 1});
+        }
+      }
+    }
+    for (const Item& it : fifo) for (int l = (int)it.depth; l <= kTopLevels; ++l) ++out->top_groups[l];
+    // (all top-level groups are numbered now; their deeper children follow, subtree by subtree)
+    // the groups of the deepest top level: their internal slots (candidates recomputed as fill_group found them)
+    for (const Item& it : fifo) {
+      if (it.depth < (uint32_t)kTopLevels) continue;
+      uint32_t cand[4]; int nc = 0;
+      const uint32_t kids[2] = {bin[it.bin_node].leftFirst, bin[it.bin_node].leftFirst + 1};
+      for (int k = 0; k < 2; ++k) {
+        const BvhNode& c = bin[kids[k]];
+        if (c.count == 0) { cand[nc++] = c.leftFirst; cand[nc++] = c.leftFirst + 1; }
+        else cand[nc++] = kids[k];
+      }
+      for (int k = 0; k < nc; ++k)
+        if (bin[cand[k]].count == 0) {
+          const uint32_t child = collapse_node(bin, cand[k], q, it.depth + 1, out);
+          q[4 * (size_t)it.group + k].leftFirst = child;
+        }
+    }
     return;
   }
   // leaf root (<= 4 triangles) or empty mesh: one group holding the root itself / nothing
@@ -281,6 +329,7 @@ void collapse_to_quads(BvhBuildResult* out) {
     out->quads[k] = s;
   }
   out->quad_depth = 1;
+  for (int l = 1; l <= kTopLevels; ++l) out->top_groups[l] = 1;
   if (root.count > 0) { out->quads[0] = root; out->quad_slots = 1; }
 }
 

@@ -28,12 +28,14 @@ struct BvhBuildResult {
   std::vector<BvhNode> quads;      // traversal layout: groups of 4 sibling slots, group 0 = children of the root
   uint32_t quad_depth = 0;         // levels of groups (root group = 1)
   uint32_t quad_slots = 0;         // non-empty slots
+  uint32_t top_groups[4] = {0, 0, 0, 0};   // [l]: groups in levels 1..l (l <= kTopLevels); they are groups 0 .. top_groups[l]-1
   std::vector<BvhNode> nodes;      // binary tree the groups are collapsed from; nodes[0] = root
   std::vector<uint32_t> order;     // leaf order -> input triangle id
   uint32_t nleaves = 0;
   uint32_t max_depth = 0;          // root = depth 0
 };
 
+constexpr int kTopLevels = 3;      // levels of groups numbered breadth first (<= 1 + 4 + 16 = 21 groups): the kernels stage them in LDS
 constexpr int kMaxLeafTris = 4;    // fits the 3-bit count of the traversal stack entry (<= 7)
 constexpr int kMaxDepth = 30;      // binary depth; the collapsed tree has <= 15 levels of groups
 

@@ -462,6 +462,7 @@ extern "C" int rtx_scene_build(rtx_scene* s) {
   std::memset(&in, 0, sizeof in);
   in.ntris = ntris; in.nverts = nverts; in.nnodes = (uint32_t)s->bvh.quads.size(); in.nleaves = s->bvh.nleaves;
   in.max_depth = s->bvh.quad_depth; in.nwild = s->nwild; in.nslots = s->bvh.quad_slots;
+  in.ntop_groups = s->bvh.top_groups[kTopLevels];
   in.build_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
   if (3 * s->bvh.quad_depth > (uint32_t)kStackDepth) return fail(RTX_ELIMIT, "BVH depth %u exceeds the traversal stack", s->bvh.quad_depth);
   // a node entry is a group index whose byte offset (index * 64) the kernels keep in 32 bits
@@ -563,7 +564,7 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   d.slights = s->d_slights.as<float4>(); d.leafboxes = s->d_leafboxes.as<float4>();
   d.leaf_faces = s->d_leaf_faces.as<int>(); d.face_pos = s->d_face_pos.as<int>();
   d.nsl = (uint32_t)(s->slights.size() / 4); d.nleafboxes = (uint32_t)nleaf;
-  d.flags = s->flags & RTX_FLAG_NO_ROOT_GATE; d.pad1 = 0;
+  d.flags = s->flags & RTX_FLAG_NO_ROOT_GATE; d.ntop = s->bvh.top_groups[kTopLevels];
   // Shader's shadowed branch (src/flyscene.cpp:731-743) colours a blocked light with the
   // *blocker's* Ka, Kd, Ks, Ns, d.  When every face and sphere has an in-range material and all
   // those records agree in these fields, any blocker gives the same colour and shadow rays may

@@ -35,8 +35,27 @@ namespace rtx {
 
 constexpr int kBlock = 256;          // 4 waves of 64
 constexpr int kStackDepth = 48;      // per-lane traversal stack entries in total (<= 3 per level of 4-node groups, <= 15 levels)
-constexpr int kLdsStack = 13;        // the first entries live in LDS (13 KB + 9 KB of parked rays per block -> 7 blocks per CU);
 constexpr int kLdsStackGroups = 16;  // same for the group-by-group scheduler, which parks nothing
+// Node groups of the top levels of the hierarchy kept in LDS per block (64 B each; 21 = three levels, 5 = two, 0 = none),
+// per scheduler.  Measured: the group-by-group kernels, whose 64 rays start at the root together, issue 10 %
+// fewer vector memory instructions with three levels staged (bunny shadow launch +3 %, camera launch -1 %); the refilling
+// kernels, whose lanes are at all depths at once, gain nothing (a wave's load costs the L1 path the same however few
+// lanes take part: -0.6 % TA wavefronts) and would have to give a stack level for the room (-1 %): 0 there.
+#ifndef RTX_TOP_GROUPS
+#define RTX_TOP_GROUPS 21
+#endif
+#ifndef RTX_TOP_GROUPS_REFILL
+#define RTX_TOP_GROUPS_REFILL 0
+#endif
+#ifndef RTX_TOP_UNIFORM
+#define RTX_TOP_UNIFORM 1            // 1: the LDS copy is read only when every stepping lane of the wave is in the top levels
+#endif
+constexpr int kTopGroups = RTX_TOP_GROUPS;
+constexpr int kTopGroupsRefill = RTX_TOP_GROUPS_REFILL;
+// The first entries of a lane's traversal stack live in LDS, deeper ones (rare) in a per-thread global column.  Per block of the
+// refilling kernels: 4 B x 256 x kLdsStack of stack + 9 KB of parked rays + 64 B per staged group -> 7 blocks per CU of 160 KB
+// with 13 levels and up to 5 groups, or 12 levels and up to 21 groups.
+constexpr int kLdsStack = kTopGroupsRefill > 5 ? 12 : 13;
                                      // deeper ones (rare) spill to a per-thread global column
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr float kPrecision = 0.001f; // Intersect::Face::precision (src/Intersect.h:14)
@@ -60,7 +79,8 @@ struct DevScene {
   const int* face_pos;     // mesh face id -> position in tris
   uint32_t ntris, nspheres, nlights, nmats;
   uint32_t nsl, nleafboxes;
-  uint32_t flags, pad1;           // bit 0: skip the reference's root-box gate (intersectTriangle semantics); bit 1: any blocker
+  uint32_t flags, ntop;           // ntop: node groups 0 .. ntop-1 are the top levels of the hierarchy (breadth first), staged in LDS
+                                  // bit 0: skip the reference's root-box gate (intersectTriangle semantics); bit 1: any blocker
                                   // shades alike; bits 2-5: reflection / refraction weights zero for all or for no material (rtx.hip)
                                   // bit 1: every material shades a blocked light alike (set at commit)
   float root_lo[3], root_hi[3];   // Box(mesh) of the reference, used as its root gate
@@ -313,13 +333,44 @@ __device__ __forceinline__ Work make_work(uint32_t n, uint32_t grab, uint32_t* c
 // One traversal step over the packed group of 4 sibling nodes *cur: slab tests against the
 // padded (and outward-quantised) boxes, near-to-far order, the other hits pushed far-to-near.  Returns false when no
 // child is hit (the caller pops); else *cur = the nearest child.
-template <class StackT>
-__device__ __forceinline__ bool node_step(const DevScene& S, const StackT& stk, float lim, float ivx, float ivy, float ivz, float oix,
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4 lds_u4;
+// The top levels of the hierarchy in LDS: every ray walks them, and a lane that reads them there does not
+// wait for (or occupy) the L1 path.  Loaded once per block.
+template <int kTop>
+struct TopLevels { static constexpr int kMax = kTop; const lds_u4* lds; uint32_t n; };
+template <int kTop>
+__device__ __forceinline__ TopLevels<kTop> load_top_levels(const DevScene& S, uint4* lds_top) {
+  TopLevels<kTop> T; T.lds = (const lds_u4*)lds_top; T.n = 0;
+  if constexpr (kTop > 0) {
+    T.n = S.ntop < (uint32_t)kTop ? S.ntop : (uint32_t)kTop;
+    for (uint32_t i = threadIdx.x; i < 4u * T.n; i += kBlock) lds_top[i] = S.nodes[i];
+    __syncthreads();
+  }
+  return T;
+}
+template <class StackT, class TopT>
+__device__ __forceinline__ bool node_step(const DevScene& S, const TopT& top, const StackT& stk, float lim, float ivx, float ivy, float ivz, float oix,
                                           float oiy, float oiz, uint32_t* cur, int* sp_io) {
   int sp = *sp_io;
-  // one 64-byte packed group of 4 sibling nodes per step (uniform base + 32-bit byte offset)
-  const uint4* q = (const uint4*)((const char*)S.nodes + (*cur << 6));
-  const uint4 h0 = q[0], h1 = q[1], h2 = q[2], h3 = q[3];
+  // one 64-byte packed group of 4 sibling nodes per step: from LDS for the top levels, else from memory (uniform
+  // base + 32-bit byte offset)
+  uint4 h0, h1, h2, h3;
+#if RTX_TOP_UNIFORM
+  // (only when every lane of the wave that steps is in the top levels: one branch for the wave, and the loads
+  //  from memory -- which cost the L1 path the same however few lanes take part -- are then really skipped)
+  if (TopT::kMax > 0 && __ballot(*cur >= top.n) == 0) {
+#else
+  if (TopT::kMax > 0 && *cur < top.n) {
+#endif
+    const lds_u4* q = top.lds + (*cur << 2);
+    const u32x4 a = q[0], b = q[1], c = q[2], d = q[3];
+    h0 = make_uint4(a.x, a.y, a.z, a.w); h1 = make_uint4(b.x, b.y, b.z, b.w);
+    h2 = make_uint4(c.x, c.y, c.z, c.w); h3 = make_uint4(d.x, d.y, d.z, d.w);
+  } else {
+    const uint4* q = (const uint4*)((const char*)S.nodes + (*cur << 6));
+    h0 = q[0]; h1 = q[1]; h2 = q[2]; h3 = q[3];
+  }
   // planes are origin + byte * step per axis; fold origin, step and the ray into one fma per plane
   const float ax = __uint_as_float(h0.w) * ivx, ay = __uint_as_float(h3.z) * ivy, az = __uint_as_float(h3.w) * ivz;
   const float bx = __builtin_fmaf(__uint_as_float(h0.x), ivx, -oix);
@@ -448,7 +499,7 @@ constexpr int kBlockMin = RTX_BLOCK_MIN;
 constexpr int kWbufWords = 9;             // o.xyz, d.xyz, best.t, best.id, slot
 
 template <class Source>
-__device__ __forceinline__ void trace_wave(const DevScene& S, const Source& src, Work work, const Stack<kLdsStack>& stk, lds_u32* wbuf,
+__device__ __forceinline__ void trace_wave(const DevScene& S, const TopLevels<kTopGroupsRefill>& top, const Source& src, Work work, const Stack<kLdsStack>& stk, lds_u32* wbuf,
                                            uint32_t tri_min, uint2* hits) {
   const uint32_t lane = threadIdx.x & 63;
   uint32_t nbuf = 0;                       // parked rays (wave-uniform)
@@ -542,7 +593,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& S, const Source& src,
     const uint64_t node_mask = __ballot(at_node);
     bool pop = false;
     if (at_node) {
-      pop = !node_step(S, stk, best.t * kPruneSlack, ivx, ivy, ivz, oix, oiy, oiz, &cur, &sp);
+      pop = !node_step(S, top, stk, best.t * kPruneSlack, ivx, ivy, ivz, oix, oiy, oiz, &cur, &sp);
     }
     if (leaf_mask != 0 && (node_mask == 0 || __popcll(leaf_mask) >= kDeferMin || __popcll(leaf_mask & ~node_mask) >= kBlockMin)) {
       // One triangle per lane and pass; passes go on while at least tri_min lanes still have
@@ -576,7 +627,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& S, const Source& src,
 // closed surfaces); the refilling scheduler above wins on incoherent work (triangle soups,
 // diffuse bounces).
 template <class Source>
-__device__ __forceinline__ void trace_wave_groups(const DevScene& S, const Source& src, Work work, const Stack<kLdsStackGroups>& stk,
+__device__ __forceinline__ void trace_wave_groups(const DevScene& S, const TopLevels<kTopGroups>& top, const Source& src, Work work, const Stack<kLdsStackGroups>& stk,
                                                   uint2* hits) {
   const uint32_t lane = threadIdx.x & 63;
   uint32_t base;
@@ -607,7 +658,7 @@ __device__ __forceinline__ void trace_wave_groups(const DevScene& S, const Sourc
         int sp = 0;
         for (;;) {
           if ((int)cur >= 0) {
-            if (node_step(S, stk, best.t * kPruneSlack, ivx, ivy, ivz, oix, oiy, oiz, &cur, &sp)) continue;
+            if (node_step(S, top, stk, best.t * kPruneSlack, ivx, ivy, ivz, oix, oiy, oiz, &cur, &sp)) continue;
           } else {
             const uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
             for (uint32_t k = first; k < first + cnt; ++k) test_triangle(S, k, o, d, &best);
@@ -631,13 +682,16 @@ __global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_tra
                                                           uint2* hits) {
   __shared__ uint32_t lds_stack[(kRefill ? kLdsStack : kLdsStackGroups) * kBlock];
   CameraSource src; src.C = C;
+  constexpr int kTop = kRefill ? kTopGroupsRefill : kTopGroups;
+  __shared__ uint4 lds_top[kTop > 0 ? 4 * kTop : 1];
+  const TopLevels<kTop> top = load_top_levels<kTop>(S, lds_top);
   __shared__ uint32_t lds_ctr;
   const Work work = make_work(nblocks * (uint32_t)kBlock, grab, &lds_ctr);
   if constexpr (kRefill) {
     __shared__ uint32_t lds_wbuf[(kBlock / 64) * kWbufWords * 64];
-    trace_wave(S, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), tri_min, hits);
+    trace_wave(S, top, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), tri_min, hits);
   } else {
-    trace_wave_groups(S, src, work, make_stack<kLdsStackGroups>(lds_stack, ovf), hits);
+    trace_wave_groups(S, top, src, work, make_stack<kLdsStackGroups>(lds_stack, ovf), hits);
   }
 }
 
@@ -647,13 +701,16 @@ __global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_tra
                                                          uint32_t bounded, uint32_t grab, uint32_t tri_min, uint32_t* ovf, uint2* hits) {
   __shared__ uint32_t lds_stack[(kRefill ? kLdsStack : kLdsStackGroups) * kBlock];
   QueueSource src; src.rays = rays; src.bounded = bounded; src.anyhit = ((bounded & 2u) && (S.flags & 2u)) ? 1u : 0u;
+  constexpr int kTop = kRefill ? kTopGroupsRefill : kTopGroups;
+  __shared__ uint4 lds_top[kTop > 0 ? 4 * kTop : 1];
+  const TopLevels<kTop> top = load_top_levels<kTop>(S, lds_top);
   __shared__ uint32_t lds_ctr;
   const Work work = make_work(*count * stride, grab, &lds_ctr);
   if constexpr (kRefill) {
     __shared__ uint32_t lds_wbuf[(kBlock / 64) * kWbufWords * 64];
-    trace_wave(S, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), tri_min, hits);
+    trace_wave(S, top, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), tri_min, hits);
   } else {
-    trace_wave_groups(S, src, work, make_stack<kLdsStackGroups>(lds_stack, ovf), hits);
+    trace_wave_groups(S, top, src, work, make_stack<kLdsStackGroups>(lds_stack, ovf), hits);
   }
 }
 
