@@ -133,7 +133,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=6144, help="primary rays in the cpu_baseline sample")
     ap.add_argument("--roofline-stride", type=int, default=16, help="every k-th pixel feeds the byte count")
     ap.add_argument("--no-scaling-proxy", action="store_true")
-    ap.add_argument("--inflight", type=int, default=3, choices=[1, 2, 3, 4],
+    ap.add_argument("--inflight", type=int, default=3, choices=[1, 2, 3, 4, 5, 6, 7, 8],
                     help="frames in flight (rtx_render_*_enqueue): they run side by side on the GPU, each on its own streams")
     args = ap.parse_args()
 

@@ -200,6 +200,25 @@ int rtx_camera_points(rtx_scene*, const rtx_camera*, const float* ij, uint32_t n
  * src/Intersect.cpp:67-145): the slab-test t (may be negative), INFINITY on a miss. */
 int rtx_intersect_box(rtx_scene*, const float* bmin_xyz, const float* bmax_xyz, const float* origin_xyz,
                       const float* dir_xyz, uint32_t n, float* t);
+/* Flyscene::trace_global_illum(Ray(o, d)) for n rays (src/flyscene.cpp:631-669): closest hit over the spheres and the
+ * reference's flat leaf list (not the BVH: the leaf lists are lossy and the answer depends on it);
+ * kd_t4 = {Kd.x, Kd.y, Kd.z, t} per ray, zeros when nothing is hit.  Needs the reference leaf list before commit. */
+int rtx_trace_gi(rtx_scene*, const float* origin_xyz, const float* dir_xyz, uint32_t n, float* kd_t4);
+
+/* Intersect::Triangle / Plane / BoxObject / Sphere ::intersects(Ray&) (src/Intersect.h:8-89, src/Intersect.cpp:6-193)
+ * for n Ray objects against one primitive; needs no scene, only a device.  origin / dir are the Ray's members as
+ * they stand (its constructor has normalised dir; nothing is normalised again).  prim: RTX_PRIM_TRIANGLE {v0, v1,
+ * v2, normal} (12 floats), RTX_PRIM_PLANE {v0, normal} (6), RTX_PRIM_BOX {tmin, tmax} (6), RTX_PRIM_SPHERE {centre,
+ * radius} (4).  Outputs are the HitInfo members the reference returns: t (INFINITY on a miss; for the box the slab
+ * distance, which may be negative), face_id (0 for a triangle / plane hit, else -1), normal, point (zeros where the
+ * reference leaves them unset); face_id / normal / point may be NULL. */
+#define RTX_PRIM_TRIANGLE 0
+#define RTX_PRIM_PLANE 1
+#define RTX_PRIM_BOX 2
+#define RTX_PRIM_SPHERE 3
+int rtx_intersect_primitive(int device, int32_t kind, const float* prim, const float* origin_xyz, const float* dir_xyz, uint32_t n,
+                            float* t, int32_t* face_id, float* normal_xyz, float* point_xyz);
+
 /* The hit search of Flyscene::ReflectDebugRay (src/flyscene.cpp:324-357) for n rays (o, d = its
  * origin / dir arguments): closest triangle over the reference's leaf list, a leaf being scanned
  * when the origin is inside its box (Box::isInBox, src/box.h:87-93) or the slab test gives t > 0;

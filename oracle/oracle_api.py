@@ -322,6 +322,17 @@ class Scene:
                                 max_segs, flags.ctypes.data_as(C.POINTER(C.c_uint8)), fp(ls), len(ls), C.byref(nls))
         return segs[:k], faces[:k], flags[:self.num_leaves()], ls[:nls.value]
 
+    def trace_gi(self, o, d):
+        """Flyscene::trace_global_illum(Ray(o, d)): [n, 4] = (Kd, t), zeros where nothing is hit."""
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        out = np.zeros((len(o), 4), np.float32)
+        L = lib()
+        L.ora_trace_gi.restype = None
+        L.ora_trace_gi.argtypes = [C.c_void_p, _f, _f, C.c_int, _f]
+        L.ora_trace_gi(self.h, fp(o), fp(d), len(o), fp(out))
+        return out
+
     def visible(self, light, pos):
         light = np.ascontiguousarray(light, np.float32).reshape(-1, 3)
         pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)

@@ -7,6 +7,12 @@
 //   * tucano/camera.hpp          Tucano::Camera::screenToWorld / getCenter
 //   * Eigen 3.3.7 (vendored)     normalized / cross / Affine inverse, as used by
 //                                tucano/mesh.hpp:461-463 and src/flyscene.cpp:839
+//   * src/box.h                  Box(tmin, tmax), Box::isInBox
+// Box(Tucano::Mesh) / Mesh::createFaces (src/box.h:41-85, tucano/mesh.hpp:441-468) were tried too: a Tucano::Mesh
+// cannot be constructed without an OpenGL context and library -- the probe links with __glewGenVertexArrays,
+// __glewBindVertexArray, __glewDeleteVertexArrays, __glewBindBuffer, __glew{Enable,Disable}VertexAttribArray,
+// __glewVertexAttribPointer, __glewPatchParameteri, glDrawArrays, glDrawElements, glGetError undefined and does not
+// load -- so the root box and the face order stay pinned by SURVEY 8(c)'s recorded outputs (no stand-ins are written).
 // Nothing of the reference is copied: this file only *calls* it.  flyscene.cpp
 // itself cannot be linked here without GL/GLEW/GLFW libraries (absent in the
 // image), so the drivers above these primitives (getIntersections, traceRay,
@@ -89,6 +95,11 @@ void ref_renormal(const float* n, float* out) {
   Eigen::Affine3f M = Eigen::Affine3f::Identity() * Eigen::Affine3f::Identity();
   Vector3f r = (M.inverse().matrix().transpose() * Eigen::Vector4f(n[0], n[1], n[2], 0)).head<3>().normalized();
   S(out, r);
+}
+// Box::isInBox  (src/box.h:87-93)
+int ref_is_in_box(const float* bmin, const float* bmax, const float* p) {
+  Box b(V(bmin), V(bmax));
+  return b.isInBox(V(p)) ? 1 : 0;
 }
 float ref_dot(const float* a, const float* b) { return V(a).dot(V(b)); }
 float ref_norm(const float* a) { return V(a).norm(); }

@@ -674,13 +674,17 @@ static void merge_counts(ora_scene* s, const counters* cn) {
 /* The hit search of Flyscene::ReflectDebugRay (src/flyscene.cpp:324-357) for one (origin, dir):
  * leaf list in order; a leaf is scanned when Box::isInBox(origin) (src/box.h:87-93) or when
  * intersectBox gives t != INFINITY && t > 0 (then the box is recorded, ray_hitbox); strict <. */
+/* Box::isInBox (src/box.h:87-93): closed on every side. */
+static int is_in_box(v3 bmin, v3 bmax, v3 p) {
+  return (p.x >= bmin.x && p.x <= bmax.x) && (p.y >= bmin.y && p.y <= bmax.y) && (p.z >= bmin.z && p.z <= bmax.z);
+}
+int ora_is_in_box(const float* bmin, const float* bmax, const float* p) { return is_in_box(ld3(bmin), ld3(bmax), ld3(p)); }
 static ora_hit debug_hit(const ora_scene* s, v3 origin, v3 dir, uint8_t* box_flags) {
   ora_hit best = hit_miss();
   float smallestT = INFINITY;
   for (int b = 0; b < s->nleaves; ++b) {
     const leaf_t* L = &s->leaves[b];
-    int scan = (origin.x >= L->bmin.x && origin.x <= L->bmax.x) && (origin.y >= L->bmin.y && origin.y <= L->bmax.y) &&
-               (origin.z >= L->bmin.z && origin.z <= L->bmax.z);
+    int scan = is_in_box(L->bmin, L->bmax, origin);
     if (!scan) {
       float bt = intersect_box(L->bmin, L->bmax, origin, dir);
       if (bt != INFINITY && bt > 0) { scan = 1; if (box_flags) box_flags[b] = 1; }
@@ -732,6 +736,10 @@ int ora_debug_ray(const ora_scene* s, const float* origin, const float* dir, int
 
 void ora_ray_counts(const ora_scene* s, uint64_t out[5]) { for (int i = 0; i < 5; ++i) out[i] = s->counts[i]; }
 
+/* Flyscene::trace_global_illum(Ray(o, d)) for n rays: {Kd.x, Kd.y, Kd.z, t}, zeros when nothing is hit. */
+void ora_trace_gi(const ora_scene* s, const float* o, const float* d, int n, float* kd_t4) {
+  for (int i = 0; i < n; ++i) { ray_t r = make_ray(ld3(o + 3 * i), ld3(d + 3 * i)); trace_gi(s, &r, kd_t4 + 4 * i); }
+}
 void ora_closest(const ora_scene* s, const float* o, const float* d, int n, ora_hit* out) {
   for (int i = 0; i < n; ++i) {
     ray_t r = make_ray(ld3(o + 3 * i), ld3(d + 3 * i));

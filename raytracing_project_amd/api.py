@@ -53,7 +53,7 @@ SYMBOLS = ["rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_
            "rtx_get_stats", "rtx_scene_build_reference_leafboxes", "rtx_scene_set_leafboxes",
            "rtx_scene_get_leafboxes", "rtx_intersect_box", "rtx_trace_shade", "rtx_camera_points", "rtx_scene_set_flags",
            "rtx_scene_get_packed_bvh", "rtx_debug_hit", "rtx_trace_closest_noalloc", "rtx_scene_clone", "rtx_render_multi",
-           "rtx_render_multi_dev"]
+           "rtx_render_multi_dev", "rtx_intersect_primitive", "rtx_trace_gi"]
 
 NOALLOC_MAX_RAYS = 65536
 FLAG_NO_ROOT_GATE, FLAG_SCHED_REFILL, FLAG_SCHED_GROUPS, FLAG_SCHED_SPLIT = 1, 2, 4, 8
@@ -103,6 +103,8 @@ def lib():
         L.rtx_scene_get_bvh.argtypes = [C.c_void_p, _u, _u]
         L.rtx_trace_closest.argtypes = [C.c_void_p, _f, _f, C.c_uint32, _f, _i, _f, _f, _i]
         L.rtx_trace_closest_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.rtx_intersect_primitive.argtypes = [C.c_int, C.c_int32, _f, _f, _f, C.c_uint32, _f, _i, _f, _f]
+        L.rtx_trace_gi.argtypes = [C.c_void_p, _f, _f, C.c_uint32, _f]
         L.rtx_scene_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.rtx_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(Camera), C.POINTER(Options), Rect, C.c_int32, _f, _f, _i]
         L.rtx_render_multi_dev.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(Camera), C.POINTER(Options), Rect, C.c_int32,
@@ -323,6 +325,14 @@ class Scene:
         """rtx_trace_closest_noalloc: device pointers, at most NOALLOC_MAX_RAYS rays, no allocation inside."""
         _check(lib().rtx_trace_closest_noalloc(self.h, o_ptr, d_ptr, n, t_ptr, face_ptr))
 
+    def trace_gi(self, o, d):
+        """rtx_trace_gi: Flyscene::trace_global_illum(Ray(o, d)) -> [n, 4] (Kd, t)."""
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        out = np.zeros((len(o), 4), np.float32)
+        _check(lib().rtx_trace_gi(self.h, fp(o), fp(d), len(o), fp(out)))
+        return out
+
     def trace_visible(self, light, pos):
         light = np.ascontiguousarray(light, np.float32).reshape(-1, 3)
         pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
@@ -403,3 +413,18 @@ def render_multi_dev(scenes, cam, opts, rect, tile_size, rgb_ptr, t_ptr, face_pt
     hs = (C.c_void_p * len(scenes))(*[s.h for s in scenes])
     _check(lib().rtx_render_multi_dev(hs, len(scenes), C.byref(cam), C.byref(opts), Rect(x0, y0, x1, y1), tile_size,
                                       rgb_ptr, t_ptr, face_ptr))
+
+
+PRIM_TRIANGLE, PRIM_PLANE, PRIM_BOX, PRIM_SPHERE = 0, 1, 2, 3
+
+
+def intersect_primitive(kind, prim, o, d, device=0):
+    """rtx_intersect_primitive: Intersect::X::intersects(Ray&) for n Ray objects (o, d as the Ray holds them) -> (t, face, normal, point)."""
+    prim = np.ascontiguousarray(prim, np.float32).reshape(-1)
+    o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+    n = len(o)
+    t = np.zeros(n, np.float32); face = np.zeros(n, np.int32)
+    nrm = np.zeros((n, 3), np.float32); pt = np.zeros((n, 3), np.float32)
+    _check(lib().rtx_intersect_primitive(device, kind, fp(prim), fp(o), fp(d), n, fp(t), face.ctypes.data_as(_i), fp(nrm), fp(pt)))
+    return t, face, nrm, pt

@@ -64,7 +64,10 @@ struct EventPool {
 }  // namespace
 
 // Calls that may be in flight on one scene (rtx_render_*_enqueue): each has its own streams and workspace.
-constexpr int kSlots = 4;
+#ifndef RTX_SLOTS
+#define RTX_SLOTS 4
+#endif
+constexpr int kSlots = RTX_SLOTS;
 
 struct rtx_scene {
   // host description
@@ -860,7 +863,10 @@ static bool overlap_frames(const rtx_scene* s) {
 // the launch is small and the other calls in flight take the CUs left free -- no gain on any workload: with
 // fewer waves per SIMD every step waits for its loads instead.)
 static uint32_t trace_blocks(rtx_scene* s, uint64_t quads) {
-  return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(quads, 1), (uint64_t)trace_grid(s));
+  uint64_t g = std::max<uint64_t>(quads, 1);
+  static const uint32_t upw = [] { const char* e = std::getenv("RTX_UPW"); const long x = e ? std::atol(e) : 0; return x > 0 ? (uint32_t)x : 1u; }();   // (experiment hook)
+  if (upw > 1 && cur_call(s).throughput) g = std::max<uint64_t>((g + upw - 1) / upw, std::min<uint64_t>(g, (uint64_t)s->ncu));
+  return (uint32_t)std::min<uint64_t>(g, (uint64_t)trace_grid(s));
 }
 static int launch_trace_camera(rtx_scene* s, const DevCamera& C, uint32_t tiles, uint2* hits) {
   const uint32_t grid = trace_blocks(s, tiles);
@@ -1428,6 +1434,87 @@ extern "C" int rtx_render(rtx_scene* s, const rtx_camera* cam, const rtx_options
   if (t) HIP_TRY(hipMemcpy(t, s->w_io[1].p, npix * 4, hipMemcpyDeviceToHost));
   if (face) HIP_TRY(hipMemcpy(face, s->w_io[2].p, npix * 4, hipMemcpyDeviceToHost));
   return RTX_OK;
+}
+
+// Flyscene::trace_global_illum(Ray(o, d)) for n caller rays (src/flyscene.cpp:631-669): {Kd of the closest hit over the
+// spheres and the reference's flat leaf list, t}; zeros when nothing is hit.
+extern "C" int rtx_trace_gi(rtx_scene* s, const float* o, const float* d, uint32_t n, float* kd_t4) {
+  if (int rc = check_ready(s)) return rc;
+  if (!s->have_leaves) return fail(RTX_ESTATE, "trace_global_illum walks the reference leaf list (rtx_scene_build_reference_leafboxes) before commit");
+  if (n == 0) return RTX_OK;
+  if (!o || !d || !kd_t4) return fail(RTX_EINVAL, "null argument");
+  if (n >= (1u << 31)) return fail(RTX_ELIMIT, "too many rays");
+  if (int rc = stats_begin(s)) return rc;
+  const size_t b3 = (size_t)n * 12;
+  if (int rc = s->w_io[0].ensure(b3)) return rc;
+  if (int rc = s->w_io[1].ensure(b3)) return rc;
+  if (int rc = s->w_io[2].ensure((size_t)n * 8)) return rc;
+  if (int rc = ws(s).w_rays[0].ensure((size_t)n * 32)) return rc;
+  if (int rc = ws(s).w_counters.ensure(64)) return rc;
+  HIP_TRY(hipMemcpyAsync(s->w_io[0].p, o, b3, hipMemcpyHostToDevice, ws(s).stream));
+  HIP_TRY(hipMemcpyAsync(s->w_io[1].p, d, b3, hipMemcpyHostToDevice, ws(s).stream));
+  HIP_TRY(hipMemcpyAsync(ws(s).w_counters.p, &n, 4, hipMemcpyHostToDevice, ws(s).stream));
+  hipLaunchKernelGGL(k_make_rays, dim3((n + 255) / 256), dim3(256), 0, ws(s).stream, s->w_io[0].as<float>(), s->w_io[1].as<float>(), n,
+                     ws(s).w_rays[0].as<float4>());
+  span_begin(s, true);
+  hipLaunchKernelGGL(k_trace_gi, dim3(grid_for(s, n)), dim3(kBlock), 0, ws(s).stream, s->dev, ws(s).w_rays[0].as<float4>(),
+                     ws(s).w_counters.as<uint32_t>(), 1u, s->w_io[2].as<uint2>());
+  span_end(s, true);
+  cur_call(s).stats.rays_gi = n;
+  if (int rc = stats_end(s)) return rc;
+  std::vector<uint2> res(n);
+  HIP_TRY(hipMemcpy(res.data(), s->w_io[2].p, (size_t)n * 8, hipMemcpyDeviceToHost));
+  for (uint32_t i = 0; i < n; ++i) {
+    float* out = kd_t4 + 4 * (size_t)i;
+    float t; std::memcpy(&t, &res[i].x, 4);
+    if (res[i].x == 0u) { out[0] = out[1] = out[2] = out[3] = 0.0f; continue; }
+    const int m = (int)res[i].y;
+    // materials[-1] is out of bounds in the reference; the library's convention everywhere: the default Mtl
+    const float dflt[3] = {0.5f, 0.5f, 0.5f};
+    const float* kd = (m >= 0 && m < (int)s->mats.size()) ? s->mats[m].kd : dflt;
+    out[0] = kd[0]; out[1] = kd[1]; out[2] = kd[2]; out[3] = t;
+  }
+  return RTX_OK;
+}
+
+// Intersect::{Triangle, Plane, BoxObject, Sphere}::intersects(Ray&) (src/Intersect.h:8-89, src/Intersect.cpp:6-193):
+// n Ray objects against one primitive, no scene needed.  Host pointers; a one-off query (it allocates and frees
+// its own device buffers).
+extern "C" int rtx_intersect_primitive(int device, int32_t kind, const float* prim, const float* o, const float* d, uint32_t n,
+                                       float* t, int32_t* face_id, float* normal, float* point) {
+  if (kind < RTX_PRIM_TRIANGLE || kind > RTX_PRIM_SPHERE) return fail(RTX_EINVAL, "unknown primitive kind %d", kind);
+  if (n == 0) return RTX_OK;
+  if (!prim || !o || !d || !t) return fail(RTX_EINVAL, "null argument");
+  if (n >= (1u << 31)) return fail(RTX_ELIMIT, "too many rays");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(RTX_EINVAL, "device %d out of range (%d devices)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  const int nprim = kind == RTX_PRIM_TRIANGLE ? 12 : kind == RTX_PRIM_SPHERE ? 4 : 6;
+  const size_t b3 = (size_t)n * 12;
+  DevBuf buf;                                     // prim | o | d | t | face | normal | point
+  const size_t off_o = 256, off_d = off_o + b3, off_t = off_d + b3, off_f = off_t + (size_t)n * 4, off_n = off_f + (size_t)n * 4,
+               off_p = off_n + b3;
+  if (int rc = buf.ensure(off_p + b3)) return rc;
+  char* base = buf.as<char>();
+  int rc = RTX_OK;
+  auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && rc == RTX_OK) rc = fail(RTX_EHIP, "%s: %s", what, hipGetErrorString(e)); };
+  chk(hipMemcpy(base, prim, (size_t)nprim * 4, hipMemcpyHostToDevice), "hipMemcpy(prim)");
+  chk(hipMemcpy(base + off_o, o, b3, hipMemcpyHostToDevice), "hipMemcpy(o)");
+  chk(hipMemcpy(base + off_d, d, b3, hipMemcpyHostToDevice), "hipMemcpy(d)");
+  if (rc == RTX_OK) {
+    hipLaunchKernelGGL(k_primitive, dim3((n + 255) / 256), dim3(256), 0, nullptr, (int)kind, (const float*)base, (const float*)(base + off_o),
+                       (const float*)(base + off_d), n, (float*)(base + off_t), (int*)(base + off_f), (float*)(base + off_n),
+                       (float*)(base + off_p));
+    chk(hipDeviceSynchronize(), "k_primitive");
+    chk(hipGetLastError(), "k_primitive");
+  }
+  if (rc == RTX_OK) chk(hipMemcpy(t, base + off_t, (size_t)n * 4, hipMemcpyDeviceToHost), "hipMemcpy(t)");
+  if (rc == RTX_OK && face_id) chk(hipMemcpy(face_id, base + off_f, (size_t)n * 4, hipMemcpyDeviceToHost), "hipMemcpy(face)");
+  if (rc == RTX_OK && normal) chk(hipMemcpy(normal, base + off_n, b3, hipMemcpyDeviceToHost), "hipMemcpy(normal)");
+  if (rc == RTX_OK && point) chk(hipMemcpy(point, base + off_p, b3, hipMemcpyDeviceToHost), "hipMemcpy(point)");
+  buf.release();
+  return rc;
 }
 
 // ------------------------------------------------------------------ several GPUs, one process

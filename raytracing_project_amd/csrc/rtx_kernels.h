@@ -776,6 +776,48 @@ __global__ void k_ref_box(const float* o, const float* d, uint32_t n, float lx, 
   t[i] = ref_box_t(v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), d1, lo, hi);
 }
 
+// Intersect::{Triangle, Plane, BoxObject, Sphere}::intersects(Ray&) (src/Intersect.cpp:6-193) for n Ray objects against
+// one primitive: o / d are the Ray's members as they stand (the ctor has normalised d already; nothing is
+// normalised again here).  prim: triangle {v0, v1, v2, normal}, plane {v0, normal}, box {tmin, tmax}, sphere
+// {centre, radius}.  Outputs as the HitInfo the reference returns: t (INFINITY = miss), faceId (0 for a triangle
+// or plane hit, else -1), normal, point (zeros where the reference leaves them unset).
+__global__ void k_primitive(int kind, const float* prim, const float* o, const float* d, uint32_t n, float* t, int* face,
+                            float* normal, float* point) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const V3 org = v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), dir = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+  float ht = INFINITY; int id = -1;
+  V3 N = v3(0, 0, 0), P = v3(0, 0, 0);
+  if (kind == 0 || kind == 1) {
+    const V3 v0 = v3(prim[0], prim[1], prim[2]);
+    const V3 nrm = kind == 0 ? v3(prim[9], prim[10], prim[11]) : v3(prim[3], prim[4], prim[5]);
+    const float D = dot(nrm, v0);
+    const float den = dot(nrm, dir);
+    if (den != 0.0f) {
+      const float tt = (D - dot(org, nrm)) / den;
+      const V3 hp = point_on_ray(org, dir, tt);
+      bool ok = tt >= kPrecision;
+      if (ok && kind == 0) {
+        const V3 u = v3(prim[3], prim[4], prim[5]) - v0, v = v3(prim[6], prim[7], prim[8]) - v0, w = hp - v0;
+        const float uu = dot(u, u), uv = dot(u, v), vv = dot(v, v), wu = dot(w, u), wv = dot(w, v);
+        const float denom = uu * vv - uv * uv;
+        const float s1 = vv * wu - uv * wv, t1 = uu * wv - uv * wu;
+        const float sb = s1 / denom, tb = t1 / denom;
+        if (sb < 0 || tb < 0 || sb + tb > 1) ok = false;
+      }
+      if (ok) { ht = tt; id = 0; N = nrm; P = hp; }
+    }
+  } else if (kind == 2) {
+    ht = ref_box_t(org, dir, prim, prim + 3);
+  } else {
+    ht = ref_sphere_t(org, dir, make_float4(prim[0], prim[1], prim[2], prim[3]));
+    if (ht != INFINITY) { P = point_on_ray(org, dir, ht); N = normalized(P - v3(prim[0], prim[1], prim[2])); }
+  }
+  t[i] = ht; face[i] = id;
+  normal[3 * i] = N.x; normal[3 * i + 1] = N.y; normal[3 * i + 2] = N.z;
+  point[3 * i] = P.x; point[3 * i + 1] = P.y; point[3 * i + 2] = P.z;
+}
+
 // Camera::screenToWorld for caller pixel coordinates (tucano/camera.hpp:155-173): the world
 // point on the image plane (before the Ray ctor normalises the direction).
 __global__ void k_camera_points(DevCamera C, const float* ij, uint32_t n, float* world) {

@@ -127,6 +127,36 @@ class Ray {
     Vector3f newDir = dir - (2.0f * dir.dot(normal)) * normal;
     return Ray(point, newDir);
   }
+  // src/Ray.h:36-42.  pow(float, 2) and sqrt evaluate in double under libstdc++ (the build the oracle is pinned to);
+  // a negative radicand (total internal reflection) gives a NaN direction, as in the reference.
+  Ray refractRay(Vector3f normal, Vector3f point, Vector3f viewDirection, float firstIndex, float secondIndex) {
+    float dot = viewDirection.dot(normal);
+    float numerator = (float)(((double)firstIndex * (double)firstIndex) * (1.0 - (double)dot * (double)dot));
+    float root = (float)std::sqrt(1.0 - ((double)numerator / ((double)secondIndex * (double)secondIndex)));
+    Vector3f t = (firstIndex / secondIndex) * (viewDirection - dot * normal) - normal * root;
+    return Ray(point, t);
+  }
+  // src/Ray.h:43-57: the reflected direction rotated n times by 2 pi / n about the normal (Eigen::AngleAxisf's
+  // rotation matrix, Eigen/src/Geometry/AngleAxis.h:218-243).
+  std::vector<Ray> resendRay(Vector3f normal, Vector3f point, int n) {
+    std::vector<Ray> res;
+    float theta = (float)(M_PI * 2 / n);
+    const float sn = std::sin(theta), c = std::cos(theta);
+    const Vector3f sin_axis = sn * normal, cos1_axis = (1.0f - c) * normal;
+    float m[9], tmp;
+    tmp = cos1_axis.x() * normal.y(); m[1] = tmp - sin_axis.z(); m[3] = tmp + sin_axis.z();
+    tmp = cos1_axis.x() * normal.z(); m[2] = tmp + sin_axis.y(); m[6] = tmp - sin_axis.y();
+    tmp = cos1_axis.y() * normal.z(); m[5] = tmp - sin_axis.x(); m[7] = tmp + sin_axis.x();
+    m[0] = cos1_axis.x() * normal.x() + c; m[4] = cos1_axis.y() * normal.y() + c; m[8] = cos1_axis.z() * normal.z() + c;
+    Vector3f direction = reflectRay(normal, point).getDirection();
+    for (int i = 0; i < n; i++) {
+      direction = Vector3f(m[0] * direction.x() + (m[1] * direction.y() + m[2] * direction.z()),
+                           m[3] * direction.x() + (m[4] * direction.y() + m[5] * direction.z()),
+                           m[6] * direction.x() + (m[7] * direction.y() + m[8] * direction.z()));
+      res.push_back(Ray(point, direction));
+    }
+    return res;
+  }
 };
 
 // src/box.h:8-97 (value type; the GPU hierarchy lives inside librtx)
@@ -141,6 +171,71 @@ class Box {
     return (o.x() >= tmin.x() && o.x() <= tmax.x()) && (o.y() >= tmin.y() && o.y() <= tmax.y()) && (o.z() >= tmin.z() && o.z() <= tmax.z());
   }
 };
+
+// src/Intersect.h:8-89: the primitive classes with their virtual intersects(Ray&), forwarded to the GPU library
+// (rtx_intersect_primitive; nothing is intersected on the host).  `device` picks the GPU (default 0).
+namespace Intersect {
+class Face {
+ protected:
+  std::vector<Vector3f> vertices;
+  Vector3f normal;
+  const float precision = 0.001f;
+  int material_id = 0;
+  HitInfo run(int kind, const float* prim, Ray& ray) {
+    HitInfo h{INFINITY, -1, Vector3f(), Vector3f()};
+    Vector3f o = ray.getOrigin(), d = ray.getDirection();
+    rtx_check(rtx_intersect_primitive(device, kind, prim, o.v, d.v, 1, &h.t, &h.faceId, h.normal.v, h.point.v));
+    return h;
+  }
+ public:
+  int device = 0;
+  virtual HitInfo intersects(Ray& ray) = 0;
+  Face(std::vector<Vector3f> _vertices, Vector3f _normal) { vertices = _vertices; normal = _normal; }
+  Face() {}
+  Face(Vector3f center) { vertices = std::vector<Vector3f>{center}; }
+  void setMaterialID(int index) { material_id = index; }
+  int getMaterialID() { return material_id; }
+  virtual ~Face() {}
+};
+class Triangle : public Face {
+ public:
+  Triangle(std::vector<Vector3f> vertices, Vector3f normal) : Face(vertices, normal) {}
+  HitInfo intersects(Ray& ray) override {
+    if (vertices.size() < 3) throw RtxError(RTX_EINVAL, "Intersect::Triangle needs three vertices");
+    float prim[12];
+    for (int k = 0; k < 3; ++k) for (int a = 0; a < 3; ++a) prim[3 * k + a] = vertices[k][a];
+    for (int a = 0; a < 3; ++a) prim[9 + a] = normal[a];
+    return run(RTX_PRIM_TRIANGLE, prim, ray);
+  }
+};
+class Plane : public Face {
+ public:
+  Plane(std::vector<Vector3f> vertices, Vector3f normal) : Face(vertices, normal) {}
+  HitInfo intersects(Ray& ray) override {
+    if (vertices.empty()) throw RtxError(RTX_EINVAL, "Intersect::Plane needs a vertex");
+    float prim[6] = {vertices[0][0], vertices[0][1], vertices[0][2], normal[0], normal[1], normal[2]};
+    return run(RTX_PRIM_PLANE, prim, ray);
+  }
+};
+class Sphere : public Face {
+  float radius;
+ public:
+  Sphere(Vector3f center, float _radius) : Face(center) { radius = _radius; }
+  HitInfo intersects(Ray& ray) override {
+    float prim[4] = {vertices[0][0], vertices[0][1], vertices[0][2], radius};
+    return run(RTX_PRIM_SPHERE, prim, ray);
+  }
+};
+class BoxObject : public Face {
+  Box& box;
+ public:
+  BoxObject(Box& _box) : Face(), box(_box) {}
+  HitInfo intersects(Ray& ray) override {
+    float prim[6] = {box.tmin[0], box.tmin[1], box.tmin[2], box.tmax[0], box.tmax[1], box.tmax[2]};
+    return run(RTX_PRIM_BOX, prim, ray);
+  }
+};
+}  // namespace Intersect
 
 // src/Scene.h:18-78: the analytic sphere list
 class Scene {
@@ -474,6 +569,24 @@ class Flyscene {
     if (bm >= 0 && bm < (int)materials.size()) m = materials[bm];
     return std::make_pair(vis != 0, m);
   }
+  // src/flyscene.cpp:631-669: (Kd, t) of the closest hit over the spheres and the leaf list `boxes`; zeros on a miss
+  Vector4f trace_global_illum(Ray& ray) {
+    sync();
+    Vector3f o = ray.getOrigin(), d = ray.getDirection();
+    Vector4f r;
+    rtx_check(rtx_trace_gi(scene, o.v, d.v, 1, r.v));
+    return r;
+  }
+  // src/flyscene.cpp:1110-1185: the flat leaf list `boxes` (the hierarchy itself is never attached to root_box in the
+  // reference either).  Throws where the reference's split would never terminate.
+  std::vector<Box> boxes;
+  void divideBox_KD(int max_numberFaces) {
+    int leaves = rtx_scene_build_reference_leafboxes(scene, max_numberFaces, 0);
+    if (leaves < 0) throw RtxError(leaves, std::string("rtx: ") + rtx_last_error());
+    dirty = true;
+    fetch_boxes();
+    std::cout << "Number of leafs: " << boxes.size() << std::endl;            // :1184
+  }
   Vector3f getCenter() {
     sync();
     rtx_camera cam = flycamera.raw();
@@ -568,6 +681,20 @@ class Flyscene {
       rtx_check(rtx_scene_commit(r, (device + i) % ndev));
     }
   }
+  void fetch_boxes() {
+    boxes.clear();
+    uint32_t nl = 0, nf = 0;
+    if (rtx_scene_get_leafboxes(scene, nullptr, nullptr, nullptr, nullptr, nullptr, &nl, &nf) < 0) return;
+    std::vector<float> lo(3 * (size_t)nl + 1), hi(3 * (size_t)nl + 1);
+    std::vector<uint32_t> st(nl + 1), ct(nl + 1);
+    std::vector<int32_t> fa(nf + 1);
+    rtx_check(rtx_scene_get_leafboxes(scene, lo.data(), hi.data(), st.data(), ct.data(), fa.data(), nullptr, nullptr));
+    for (uint32_t i = 0; i < nl; ++i) {
+      Box b(Vector3f(lo[3 * i], lo[3 * i + 1], lo[3 * i + 2]), Vector3f(hi[3 * i], hi[3 * i + 1], hi[3 * i + 2]));
+      for (uint32_t k = 0; k < ct[i]; ++k) b.triangles.push_back(make_face(fa[st[i] + k]));
+      boxes.push_back(b);
+    }
+  }
   Tucano::Face make_face(int f) {
     Tucano::Face face;
     for (int k = 0; k < 3; ++k) face.vertex_ids.push_back(mesh.idx[3 * (size_t)f + k]);
@@ -585,6 +712,7 @@ class Flyscene {
     // Box(mesh) + divideBox_KD(sqrt(F + 100)) (src/flyscene.cpp:77-82): the leaf list the GI probes walk
     int leaves = rtx_scene_build_reference_leafboxes(scene, 0, 0);
     if (leaves < 0) { std::cerr << "warning: " << rtx_last_error() << "; global illumination probes disabled" << std::endl; options.gi_rays = 0; }
+    else fetch_boxes();
     root_box.triangles.clear();
     for (int f = 0; f < (int)mesh.tri_mat.size(); ++f) root_box.triangles.push_back(make_face(f));
     dirty = true;

@@ -2,6 +2,9 @@
 //   host_io_check obj <file.obj> <out.bin>   load with rtxhost::loadObjFile, dump the flattened arrays
 //   host_io_check ply <file.ply> <out.bin>   same for rtxhost::loadPlyFile
 //   host_io_check ppm <in.bin> <out.ppm>     in.bin = int32 W, int32 H, float rgb[H][W][3] -> writePPMImage
+//   host_io_check ray <in.bin> <out.bin>     in.bin = int32 n, then n x {o, d, normal, point, view (3 floats each), n1, n2}:
+//                                            the facade's Ray value type -> n x {Ray(o,d) (6), reflectRay (6), refractRay (6),
+//                                            resendRay(.., 8) directions (24)}
 // Dump layout: int32 nverts, ntris, nmats; float verts[nverts*3]; uint32 idx[ntris*3]; int32 tri_mat[ntris];
 // per material: float ka[3], kd[3], ks[3], ns, ni, d; int32 illum.
 #include <cstdio>
@@ -39,6 +42,32 @@ int main(int argc, char** argv) {
     const bool ok = mode == "obj" ? loadObjFile(m, mats, argv[2]) : loadPlyFile(m, argv[2]);
     if (!ok) return 1;
     return dump(m, mats, argv[3]);
+  }
+  if (mode == "ray") {
+    FILE* f = std::fopen(argv[2], "rb");
+    if (!f) return 2;
+    int32_t n = 0;
+    if (std::fread(&n, 4, 1, f) != 1 || n < 0) return 2;
+    std::vector<float> in((size_t)n * 17), out((size_t)n * 42);
+    if (std::fread(in.data(), 4, in.size(), f) != in.size()) return 2;
+    std::fclose(f);
+    auto V = [](const float* p) { return Vector3f(p[0], p[1], p[2]); };
+    auto put = [](float* q, Ray r) { Vector3f o = r.getOrigin(), d = r.getDirection(); for (int k = 0; k < 3; ++k) { q[k] = o[k]; q[3 + k] = d[k]; } };
+    for (int32_t i = 0; i < n; ++i) {
+      const float* a = &in[(size_t)i * 17];
+      float* q = &out[(size_t)i * 42];
+      Ray r(V(a), V(a + 3));
+      put(q, r);
+      put(q + 6, r.reflectRay(V(a + 6), V(a + 9)));
+      put(q + 12, r.refractRay(V(a + 6), V(a + 9), V(a + 12), a[15], a[16]));
+      std::vector<Ray> rs = r.resendRay(V(a + 6), V(a + 9), 8);
+      for (int k = 0; k < 8; ++k) { Vector3f d = rs[k].getDirection(); q[18 + 3 * k] = d[0]; q[19 + 3 * k] = d[1]; q[20 + 3 * k] = d[2]; }
+    }
+    f = std::fopen(argv[3], "wb");
+    if (!f) return 2;
+    std::fwrite(out.data(), 4, out.size(), f);
+    std::fclose(f);
+    return 0;
   }
   if (mode == "ppm") {
     FILE* f = std::fopen(argv[2], "rb");

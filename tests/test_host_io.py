@@ -162,3 +162,23 @@ def test_ppm_writer_is_byte_identical_to_the_oracle_writer(tool, oa, tmp_path):
         assert rc == 0, err
         assert oa.lib().ora_ppm_write(str(tmp_path / "e.ppm").encode(), fp(rgb), w, h, 0) == 0
         assert open(tmp_path / "o.ppm", "rb").read() == open(tmp_path / "e.ppm", "rb").read()
+
+
+def test_facade_ray_value_type_matches_the_reference_goldens(tool, tmp_path):
+    """Ray ctor, reflectRay, refractRay, resendRay of the facade's Ray (plain host arithmetic, like the reference's
+    header-only src/Ray.h:7-58) against tests/golden/primitives.npz -- outputs of the reference's own Ray.h built with
+    the vendored Eigen (oracle/_ref).  Bit for bit, NaN directions (total internal reflection) included."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "primitives.npz"))
+    n = len(z["o"])
+    rec = np.concatenate([z["o"], z["d"], z["nq"], z["p"], z["view"], z["n12"]], axis=1).astype(np.float32)
+    assert rec.shape == (n, 17)
+    with open(tmp_path / "rays.bin", "wb") as f:
+        f.write(struct.pack("<i", n)); f.write(np.ascontiguousarray(rec).tobytes())
+    rc, err = run(tool, "ray", tmp_path / "rays.bin", tmp_path / "out.bin")
+    assert rc == 0, err
+    out = np.fromfile(tmp_path / "out.bin", np.float32).reshape(n, 42)
+    for name, got in (("ray", out[:, 0:6]), ("reflect", out[:, 6:12]), ("refract", out[:, 12:18]), ("resend", out[:, 18:42])):
+        want = z[name]
+        assert np.array_equal(np.isnan(got), np.isnan(want)), name
+        assert np.array_equal(got.view(np.uint32)[~np.isnan(want)], want.view(np.uint32)[~np.isnan(want)]), name
+    assert np.isnan(z["refract"]).any()
