@@ -38,6 +38,27 @@ int main(int argc, char** argv) {
       Vector3f col = fs.traceRay(0, r, false);
       std::printf("rgb %.9g %.9g %.9g\n", col[0], col[1], col[2]);
     }
+    // the primitive classes and the GI probe by name (src/Intersect.h:8-89, src/flyscene.cpp:631-669), first rays again
+    std::printf("boxes %zu", fs.boxes.size());
+    for (auto& b : fs.boxes) std::printf(" %zu", b.triangles.size());
+    std::printf("\n");
+    in.clear(); in.seekg(0);
+    for (int k = 0; k < 10 && (in >> o[0] >> o[1] >> o[2] >> d[0] >> d[1] >> d[2]); ++k) {
+      Ray r(Vector3f(o[0], o[1], o[2]), Vector3f(d[0], d[1], d[2]));
+      Intersect::Sphere sp(Vector3f(0.1f, 0.3f, -0.2f), 0.6f);
+      HitInfo hs = sp.intersects(r);
+      std::printf("isph %.9g %d %.9g %.9g %.9g %.9g %.9g %.9g\n", hs.t, hs.faceId, hs.normal[0], hs.normal[1], hs.normal[2], hs.point[0], hs.point[1], hs.point[2]);
+      std::vector<Vector3f> tv{Vector3f(-2, 0, -2), Vector3f(2, 0, 2), Vector3f(2, 0, -2)};
+      Intersect::Triangle tr(tv, Vector3f(0, 1, 0));
+      Intersect::Face* f = &tr;                      // through the virtual, as the reference's callers do
+      HitInfo ht = f->intersects(r);
+      std::printf("itri %.9g %d %.9g %.9g %.9g\n", ht.t, ht.faceId, ht.point[0], ht.point[1], ht.point[2]);
+      Box bb(Vector3f(-1, 0, -1), Vector3f(1, 0.5f, 1));
+      Intersect::BoxObject bo(bb);
+      std::printf("ibox %.9g\n", bo.intersects(r).t);
+      Vector4f g = fs.trace_global_illum(r);
+      std::printf("gi %.9g %.9g %.9g %.9g\n", g.v[0], g.v[1], g.v[2], g.v[3]);
+    }
     // debug rays (src/flyscene.cpp:288-393): the first rays again, followed through 3 reflections
     in.clear(); in.seekg(0);
     for (int k = 0; k < 12 && (in >> o[0] >> o[1] >> o[2] >> d[0] >> d[1] >> d[2]); ++k) {

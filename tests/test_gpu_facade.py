@@ -2,6 +2,7 @@
 own callers (tests/cpp/facade_demo.cpp), checked against the oracle.  Exercises, through the
 reference's method names: initialize (OBJ/MTL import), getIntersections, intersectTriangle,
 intersectBox, canSeeLight, traceRay, ReflectDebugRay, raytraceScene (13 spheres, result.ppm)."""
+import ctypes as C
 import os
 import subprocess
 
@@ -89,6 +90,24 @@ def test_facade_matches_oracle(tmp_path, oa):
         l = next(it)
         assert l[0] == "rgb"
         assert np.allclose(f32(l[1:4]), rgb[i], rtol=1e-4, atol=1e-6)
+    # the leaf list as `boxes`, the primitive classes through their virtual intersects(Ray&), trace_global_illum
+    l = next(it)
+    assert l[0] == "boxes" and int(l[1]) == 4 and [int(x) for x in l[2:]] == [len(f) for _, _, f in o.leaves()]
+    h7 = np.zeros(7, np.float32)
+    for i in range(10):
+        l = next(it)
+        oa.lib().ora_sphere(oa.fp(org[i]), oa.fp(d[i]), oa.fp(np.float32([0.1, 0.3, -0.2])), C.c_float(0.6), oa.fp(h7))
+        assert l[0] == "isph" and int(l[2]) == -1 and np.array_equal(f32(l[1:2] + l[3:9]).view(np.uint32), h7.view(np.uint32))
+        l = next(it)
+        tv = np.float32([[-2, 0, -2], [2, 0, 2], [2, 0, -2]])
+        oa.lib().ora_triangle(oa.fp(org[i]), oa.fp(d[i]), oa.fp(tv[0]), oa.fp(tv[1]), oa.fp(tv[2]), oa.fp(np.float32([0, 1, 0])), oa.fp(h7))
+        assert l[0] == "itri" and np.array_equal(f32([l[1]] + l[3:6]).view(np.uint32), h7[[0, 4, 5, 6]].view(np.uint32))
+        assert int(l[2]) == (0 if np.isfinite(h7[0]) else -1)
+        l = next(it)
+        want_box = oa.lib().ora_box(oa.fp(org[i]), oa.fp(d[i]), oa.fp(np.float32([-1, 0, -1])), oa.fp(np.float32([1, .5, 1])))
+        assert l[0] == "ibox" and np.float32(float(l[1])) == np.float32(want_box)
+        l = next(it)
+        assert l[0] == "gi" and np.array_equal(f32(l[1:5]).view(np.uint32), o.trace_gi(org[i], d1[i])[0].view(np.uint32))
     # debug rays: ReflectDebugRay through 3 reflections for the first 12 rays (raw direction, as the demo passes it)
     for i in range(12):
         l = next(it)
