@@ -131,6 +131,7 @@ struct rtx_scene {
     uint32_t* hc = nullptr;            // pinned host copy of the pipeline's counters
     size_t hc_words = 0;
     bool pending = false;              // enqueued, not finished yet
+    bool tunable = false;              // a render call: its launches may be tuner trials (set before the first launch)
     bool throughput = false;           // enqueued, and other calls may run beside it
     bool unreported = false;           // enqueued by rtx_render_*_enqueue and not yet handed out by rtx_render_finish
     bool pipeline = false, shade = false, shadows = false, tune = false;   // what finish_call has to account for
@@ -315,6 +316,8 @@ extern "C" int rtx_scene_build_reference_leafboxes(rtx_scene* s, int32_t max_fac
   for (uint32_t i = 0; i < ntris; ++i) queue[0].faces[i] = (int32_t)i;
   size_t head = 0;
   int64_t iters = 0;
+  size_t queued_ids = ntris;                                  // face ids held by boxes still in the queue
+  const size_t id_cap = (size_t)64 * ntris + 65536;
   while (head < queue.size()) {
     if (++iters > iter_cap) return fail(RTX_ELIMIT, "the reference's divideBox_KD does not terminate on this mesh (SURVEY F13)");
     QBox box = std::move(queue[head]); ++head;
@@ -338,6 +341,12 @@ extern "C" int rtx_scene_build_reference_leafboxes(rtx_scene* s, int32_t max_fac
       if (in_box(b1.lo, b1.hi, f)) b1.faces.push_back(f);
       if (in_box(b2.lo, b2.hi, f)) b2.faces.push_back(f);
     }
+    // Every split copies a face into each child that holds one of its vertices: on a mesh whose triangles straddle the
+    // planes the queued lists can double per level, and memory would run out long before the pop cap above says so.
+    queued_ids += b1.faces.size() + b2.faces.size();
+    queued_ids -= std::min(queued_ids, box.faces.size());
+    if (queued_ids > id_cap || (b1.faces.size() == box.faces.size() && b2.faces.size() == box.faces.size() && box.faces.size() > (size_t)max_faces))
+      return fail(RTX_ELIMIT, "the reference's divideBox_KD does not terminate on this mesh (its face lists stop shrinking; SURVEY F13)");
     queue.push_back(std::move(b1));
     queue.push_back(std::move(b2));
     if (head > 4096 && head * 2 > queue.size()) { queue.erase(queue.begin(), queue.begin() + (long)head); head = 0; }
@@ -709,7 +718,7 @@ static int stats_begin(rtx_scene* s) {
   c.events.reset(); c.trace_spans.clear(); c.all_spans.clear(); c.camera_span = (size_t)-1;
   c.span_kind.clear();
   for (int k = 0; k < 3; ++k) { c.mode[k] = -1; c.timed[k] = false; }
-  c.pipeline = c.shade = c.shadows = c.tune = c.throughput = false; c.max_gen = 0; c.NLS = c.G = 0;
+  c.pipeline = c.shade = c.shadows = c.tune = c.throughput = c.tunable = false; c.max_gen = 0; c.NLS = c.G = 0;
   std::memset(&c.stats, 0, sizeof c.stats);
   span_begin(s, false);
   return RTX_OK;
@@ -778,6 +787,7 @@ static int sched_pick(rtx_scene* s, int kind, uint64_t rays) {
   rtx_scene::Tune& T = s->tune[kind];
   int m;
   if (T.choice >= 0) m = T.choice;
+  else if (!c.tunable) m = sched_heuristic(s, kind, rays);   // a query call: never accounted by tune_update, so it takes no trial
   else if (!T.started || T.too_small) { m = sched_heuristic(s, kind, rays); T.started = true; }   // first call (cold caches) and small launches: not timed
   else {
     m = 0;                                              // the mode tried least so far: groups, refill, split, twice each
@@ -1075,7 +1085,10 @@ extern "C" int rtx_tiles_count(rtx_rect rect, int32_t tile_size, int32_t part, i
   if (nparts < 1 || part < 0 || part >= nparts) return fail(RTX_EINVAL, "need 0 <= part < nparts");
   const int64_t tx = (rect.x1 - rect.x0 + tile_size - 1) / tile_size, ty = (rect.y1 - rect.y0 + tile_size - 1) / tile_size;
   const int64_t total = tx * ty;
-  return (int)((total - part + nparts - 1) / nparts);
+  if ((int64_t)(rect.x1 - rect.x0) * (int64_t)(rect.y1 - rect.y0) >= (1ll << 31)) return fail(RTX_ELIMIT, "rectangle has too many pixels");
+  const int64_t mine = (total - part + nparts - 1) / nparts;
+  if (mine >= (1ll << 31) / 256) return fail(RTX_ELIMIT, "too many tiles in a part");
+  return (int)mine;
 }
 
 // rtx_render_tiles_dev's layout undone: the compact tile buffers of all parts (one after the other,
@@ -1281,6 +1294,7 @@ static int render_impl(rtx_scene* s, const DevCamera& C, uint32_t npix, uint32_t
                        float* rgb, float* t, int32_t* face, bool wait) {
   if (int rc = stats_begin(s)) return rc;
   cur_call(s).throughput = !wait && overlap_frames(s);
+  cur_call(s).tunable = true;
   const size_t tab_cap = ws(s).w_cam_tab.cap;
   if (int rc = ws(s).w_cam_tab.ensure((size_t)(C.w + C.h) * 4)) return rc;
   if (ws(s).w_cam_tab.cap != tab_cap) ws(s).cam_tab_ok = false;      // a new allocation (maybe at the old address)

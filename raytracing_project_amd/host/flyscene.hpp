@@ -311,6 +311,11 @@ inline bool loadObjFile(MeshData& mesh, std::vector<Tucano::Material::Mtl>& mtls
       s >> x; s >> y; s >> z;
       mesh.verts.push_back(x); mesh.verts.push_back(y); mesh.verts.push_back(z);
     } else if (line.compare(0, 2, "f ") == 0) {
+      // Tucano's importer pushes EVERY item of a face record onto the group's index stream and cuts the stream into
+      // triples afterwards (objimporter.hpp:191-222, mesh.hpp:446-452): a record with four vertices is not a quad but
+      // shifts every later triple of its group by one, one with two shifts them back.  Kept as it is -- face ids and
+      // face order are the parity contract -- and pinned against the oracle's loader on such a file; feed
+      // triangulated meshes.
       std::stringstream ls(line.substr(2));
       for (std::string e; ls >> e;) groups.back().push_back((uint32_t)(atoi(e.c_str()) - 1));
     }
@@ -372,6 +377,7 @@ inline bool loadPlyFile(MeshData& mesh, const std::string& filename) {
     return true;
   };
   const size_t vert0 = mesh.verts.size() / 3;
+  for (const Elem& e : elems) if (e.count > ((size_t)1 << 31)) { std::cerr << filename << ": implausible element count" << std::endl; return false; }
   for (const Elem& e : elems) {
     for (size_t k = 0; k < e.count; ++k) {
       float xyz[3] = {0, 0, 0};
@@ -383,6 +389,7 @@ inline bool loadPlyFile(MeshData& mesh, const std::string& filename) {
         } else {
           double n;
           if (!read_number(p.count_type, &n)) { std::cerr << filename << ": truncated PLY body" << std::endl; return false; }
+          if (!(n >= 0.0 && n <= 65536.0)) { std::cerr << filename << ": truncated PLY body" << std::endl; return false; }   // (a count no polygon has)
           std::vector<uint32_t> ids((size_t)n);
           for (size_t i = 0; i < ids.size(); ++i) {
             double v;

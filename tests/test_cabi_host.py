@@ -319,3 +319,28 @@ def test_top_levels_of_the_hierarchy_are_numbered_breadth_first(api):
         assert info.ntop_groups == len(seen) <= 21
         assert all(g >= info.ntop_groups for g in level)          # the fourth level starts after them
         s.close()
+
+
+def test_leafbox_split_gives_up_on_memory_growth_not_only_on_pops(api):
+    """Flyscene::divideBox_KD copies a face into both children whenever it has a vertex in each: on a mesh of
+    triangles that all straddle every split plane the queued lists never shrink.  The builder must say RTX_ELIMIT
+    promptly instead of growing until the machine is out of memory."""
+    rng = np.random.default_rng(5)
+    n = 3000
+    # long needles through the whole scene: each has one vertex near each of two opposite corners
+    a = rng.uniform(-1.0, -0.9, (n, 3)); b = rng.uniform(0.9, 1.0, (n, 3)); c = rng.uniform(-1.0, 1.0, (n, 3))
+    verts = np.stack([a, b, c], 1).reshape(-1, 3).astype(np.float32)
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    s = api.Scene(verts, idx, None, [])
+    import time
+    t0 = time.time()
+    with pytest.raises(api.RtxError, match="does not terminate"):
+        s.build_reference_leafboxes()
+    assert time.time() - t0 < 20
+    s.close()
+
+
+def test_tiles_count_limits(api):
+    with pytest.raises(api.RtxError):
+        api.tiles_count((0, 0, 1 << 20, 1 << 12), 16, 0, 1)          # 2^32 pixels
+    assert api.tiles_count((0, 0, 3840, 2160), 32, 7, 8) == 1020      # 120 x 68 tiles

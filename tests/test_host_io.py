@@ -182,3 +182,20 @@ def test_facade_ray_value_type_matches_the_reference_goldens(tool, tmp_path):
         assert np.array_equal(np.isnan(got), np.isnan(want)), name
         assert np.array_equal(got.view(np.uint32)[~np.isnan(want)], want.view(np.uint32)[~np.isnan(want)]), name
     assert np.isnan(z["refract"]).any()
+
+
+def test_obj_polygon_records_follow_tucano_and_bad_ply_counts_are_refused(tool, oa, tmp_path):
+    """A face record with other than three vertices: Tucano pushes every item onto the index stream and cuts triples
+    afterwards, so later triangles of the group shift -- reproduced as is (face ids are the parity contract), checked
+    against the oracle's loader.  A PLY list count no polygon has is refused instead of allocated."""
+    with open(tmp_path / "quad.obj", "w") as f:
+        f.write("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0 0 1\nf 1 2 3 4\nf 1 2 5\nf 1 2\n")
+    v, idx, tm = same_as_oracle(tool, oa, tmp_path / "quad.obj", tmp_path)
+    assert idx.tolist() == [[0, 1, 2], [3, 0, 1], [4, 0, 1]]
+    hdr = "ply\nformat binary_little_endian 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\nelement face 1\nproperty list int int vertex_indices\nend_header\n"
+    body = struct.pack("<9f", 0, 0, 0, 1, 0, 0, 0, 1, 0)
+    for count in (-1, 1 << 30):
+        with open(tmp_path / "bad.ply", "wb") as f:
+            f.write(hdr.encode()); f.write(body); f.write(struct.pack("<i", count)); f.write(struct.pack("<3i", 0, 1, 2))
+        rc, err = run(tool, "ply", tmp_path / "bad.ply", tmp_path / "bad.bin")
+        assert rc == 1 and "truncated PLY body" in err
