@@ -76,6 +76,11 @@ typedef struct {
   float ms_total;      /* HIP-event time of every kernel of the call */
   uint32_t launches_trace;
   float ms_trace_camera;   /* the primary-ray traversal launch alone (0 when the call had none) */
+  uint32_t rays_out_of_domain;   /* caller / camera rays whose origin lies beyond the validity range of the culling boxes
+                                    (~30 x the largest |coordinate| of the mesh): answered by a brute-force scan of every
+                                    triangle, as the reference answers all rays, so that parity holds by construction */
+  uint32_t verify_checked;       /* RTX_FLAG_VERIFY: rays of this call re-checked by that brute-force scan ... */
+  uint32_t verify_mismatches;    /* ... and how many of them differed from the hierarchy's answer (expected: 0) */
 } rtx_stats;
 
 typedef struct {
@@ -121,6 +126,11 @@ int rtx_scene_set_lights(rtx_scene*, const float* xyz, uint32_t n, const float* 
 #define RTX_FLAG_SCHED_REFILL 2u
 #define RTX_FLAG_SCHED_GROUPS 4u
 #define RTX_FLAG_SCHED_SPLIT 8u
+/* RTX_FLAG_VERIFY: every closest-hit launch of caller or camera rays re-checks a sample of its rays (every k-th, about
+ * 2,000 per launch) by brute force over all triangles and reports the outcome in rtx_stats.verify_*: a standing
+ * check of "the BVH only skips triangles the ray cannot hit" on the caller's own scenes, at ~ntris x 2,000 triangle
+ * tests per launch.  No counterpart in the reference (which always scans every triangle). */
+#define RTX_FLAG_VERIFY 16u
 int rtx_scene_set_flags(rtx_scene*, uint32_t flags);
 
 /* Flyscene::divideBox_KD + averagePoint / axisToDivide / isInBox and Box(mesh)

@@ -34,7 +34,8 @@ class Rect(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_reflection", C.c_uint64),
                 ("rays_refraction", C.c_uint64), ("rays_gi", C.c_uint64), ("ms_trace", C.c_float),
-                ("ms_total", C.c_float), ("launches_trace", C.c_uint32), ("ms_trace_camera", C.c_float)]
+                ("ms_total", C.c_float), ("launches_trace", C.c_uint32), ("ms_trace_camera", C.c_float),
+                ("rays_out_of_domain", C.c_uint32), ("verify_checked", C.c_uint32), ("verify_mismatches", C.c_uint32)]
 
 
 class SceneInfo(C.Structure):
@@ -56,7 +57,7 @@ SYMBOLS = ["rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_
            "rtx_render_multi_dev", "rtx_intersect_primitive", "rtx_trace_gi"]
 
 NOALLOC_MAX_RAYS = 65536
-FLAG_NO_ROOT_GATE, FLAG_SCHED_REFILL, FLAG_SCHED_GROUPS, FLAG_SCHED_SPLIT = 1, 2, 4, 8
+FLAG_NO_ROOT_GATE, FLAG_SCHED_REFILL, FLAG_SCHED_GROUPS, FLAG_SCHED_SPLIT, FLAG_VERIFY = 1, 2, 4, 8, 16
 
 _lib = None
 

@@ -89,6 +89,7 @@ struct rtx_scene {
   std::vector<int32_t> h_tri_face;
   float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
   uint32_t nwild = 0;
+  float domain = INFINITY;             // ray origins beyond this |coordinate| are outside what the boxes' padding covers
   // committed state
   bool committed = false;
   int device = -1;
@@ -108,10 +109,11 @@ struct rtx_scene {
     DevBuf w_stack_ovf;                // global overflow columns of the per-lane traversal stacks
     DevBuf w_stack_ovf2;               // ... of the launches on stream2 (they run beside launches on `stream`)
     DevBuf w_rays[2], w_hits[3], w_parents, w_shadow_rays, w_shadow_hits, w_gi_rays, w_gi_hits, w_counters;
+    DevBuf w_guard;                    // counters of the domain guard / verification kernels
     DevBuf w_acc, w_acc_flag;          // fixed-point pixel sums of ray-tree calls (reflection + refraction)
     template <class F> void for_each_buf(F f) {
       f(w_cam_tab); f(w_stack_ovf); f(w_stack_ovf2); f(w_rays[0]); f(w_rays[1]); f(w_hits[0]); f(w_hits[1]); f(w_hits[2]);
-      f(w_parents); f(w_shadow_rays); f(w_shadow_hits); f(w_gi_rays); f(w_gi_hits); f(w_counters); f(w_acc); f(w_acc_flag);
+      f(w_parents); f(w_shadow_rays); f(w_shadow_hits); f(w_gi_rays); f(w_gi_hits); f(w_counters); f(w_acc); f(w_acc_flag); f(w_guard);
     }
   };
   Slot slots[kSlots];
@@ -128,6 +130,8 @@ struct rtx_scene {
     std::vector<int> span_kind;        // kind of each trace span, -1 = not a scheduler-driven launch
     int mode[3] = {-1, -1, -1};        // scheduler mode of this call per launch kind (-1: none picked yet)
     bool timed[3] = {false, false, false};   // ... and whether that pick is one of the tuner's trials
+    uint32_t* hg = nullptr;            // pinned host copy of the guard / verification counters (4 words)
+    bool guard = false;                // ... in use by this call
     uint32_t* hc = nullptr;            // pinned host copy of the pipeline's counters
     size_t hc_words = 0;
     bool pending = false;              // enqueued, not finished yet
@@ -208,6 +212,8 @@ static void release_device(rtx_scene* s) {
   for (rtx_scene::Call& c : s->calls) {
     c.events.release();
     if (c.hc) (void)hipHostFree(c.hc);
+    if (c.hg) (void)hipHostFree(c.hg);
+    c.hg = nullptr;
     c.hc = nullptr; c.hc_words = 0; c.pending = false; c.unreported = false;
   }
   s->committed = false;
@@ -237,7 +243,7 @@ extern "C" int rtx_scene_set_spheres(rtx_scene* s, const float* cr4, const int32
 
 extern "C" int rtx_scene_set_flags(rtx_scene* s, uint32_t flags) {
   if (!s) return fail(RTX_EINVAL, "null scene");
-  if (flags & ~(uint32_t)(RTX_FLAG_NO_ROOT_GATE | RTX_FLAG_SCHED_REFILL | RTX_FLAG_SCHED_GROUPS | RTX_FLAG_SCHED_SPLIT)) return fail(RTX_EINVAL, "unknown flag bits 0x%x", flags);
+  if (flags & ~(uint32_t)(RTX_FLAG_NO_ROOT_GATE | RTX_FLAG_SCHED_REFILL | RTX_FLAG_SCHED_GROUPS | RTX_FLAG_SCHED_SPLIT | RTX_FLAG_VERIFY)) return fail(RTX_EINVAL, "unknown flag bits 0x%x", flags);
   if ((flags & RTX_FLAG_SCHED_REFILL) && (flags & RTX_FLAG_SCHED_GROUPS)) return fail(RTX_EINVAL, "pick one scheduler");
   if ((flags & RTX_FLAG_SCHED_SPLIT) && !(flags & RTX_FLAG_SCHED_REFILL)) return fail(RTX_EINVAL, "RTX_FLAG_SCHED_SPLIT modifies RTX_FLAG_SCHED_REFILL");
   if ((flags ^ s->flags) & RTX_FLAG_NO_ROOT_GATE) s->committed = false;   // the scheduler bits are host-side only
@@ -391,7 +397,10 @@ extern "C" int rtx_scene_build(rtx_scene* s) {
   for (size_t i = 0; i < s->verts.size(); ++i)
     if (std::fabs(s->verts[i]) <= kCoordMax) scene_abs = std::max(scene_abs, std::fabs(s->verts[i]));
   const float pad_abs = std::max(2e-5f * scene_abs, 1e-30f);
+  s->domain = scene_abs > 0.0f ? 30.0f * scene_abs : INFINITY;        // what pad_abs is good for; beyond: brute force
   const double kWildBelow = [] { const char* e = std::getenv("RTX_WILD_BELOW"); const double v = e ? std::atof(e) : 0.0; return v > 0 ? v : 2.5e-6; }();   // (tuning / test hook)
+  // (test hook: RTX_TEST_PAD_SCALE < 0 shrinks the boxes, so that the hierarchy loses hits and RTX_FLAG_VERIFY has something to find)
+  const float kPadScale = [] { const char* e = std::getenv("RTX_TEST_PAD_SCALE"); return e ? (float)std::atof(e) : 1.0f; }();
   auto vert = [&](uint32_t i) { return v3(s->verts[3 * i], s->verts[3 * i + 1], s->verts[3 * i + 2]); };
   for (uint32_t f = 0; f < ntris; ++f) {
     const V3 a = vert(s->idx[3 * f]), b = vert(s->idx[3 * f + 1]), c = vert(s->idx[3 * f + 2]);
@@ -433,7 +442,8 @@ extern "C" int rtx_scene_build(rtx_scene* s) {
     const double lu = std::sqrt(duu), lv = std::sqrt(dvv), le = std::sqrt(dee);
     const double longest = std::max(lu, std::max(lv, le));
     const double fuzz = 3e-6 / std::sqrt(q) * (1.0 + (lu + lv) / le);
-    const float pad = pad_abs + (float)(longest * (2e-3 + fuzz) + std::max(lu, lv) * (1.2e-6 / q));
+    float pad = pad_abs + (float)(longest * (2e-3 + fuzz) + std::max(lu, lv) * (1.2e-6 / q));
+    pad *= kPadScale;
     const float pa[3] = {a.x, a.y, a.z}, pb[3] = {b.x, b.y, b.z}, pc[3] = {c.x, c.y, c.z};
     float bl[3], bh[3];
     for (int k = 0; k < 3; ++k) {
@@ -500,6 +510,8 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   for (rtx_scene::Slot& w : s->slots) if (!w.stream) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
   for (rtx_scene::Slot& w : s->slots) if (!w.stream2) HIP_TRY(hipStreamCreateWithFlags(&w.stream2, hipStreamNonBlocking));
   if (int rc = scratch_init(device)) return rc;
+  for (rtx_scene::Slot& w : s->slots) if (int rc = w.w_guard.ensure(64)) return rc;
+  for (rtx_scene::Call& c : s->calls) if (!c.hg) HIP_TRY(hipHostMalloc((void**)&c.hg, 64, hipHostMallocDefault));
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   s->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -699,6 +711,7 @@ static int finish_call(rtx_scene* s, rtx_scene::Call& c) {
       if (g < c.max_gen) { c.stats.rays_refraction += hc[4 * g + 2]; c.stats.rays_reflection += hc[4 * g + 1] - hc[4 * g + 2]; }
     }
   }
+  if (c.guard) { c.stats.rays_out_of_domain = c.hg[0]; c.stats.verify_checked = c.hg[1]; c.stats.verify_mismatches = c.hg[2]; }
   if (c.tune) tune_update(s, c);
   s->stats = c.stats;
   return RTX_OK;
@@ -718,13 +731,14 @@ static int stats_begin(rtx_scene* s) {
   c.events.reset(); c.trace_spans.clear(); c.all_spans.clear(); c.camera_span = (size_t)-1;
   c.span_kind.clear();
   for (int k = 0; k < 3; ++k) { c.mode[k] = -1; c.timed[k] = false; }
-  c.pipeline = c.shade = c.shadows = c.tune = c.throughput = c.tunable = false; c.max_gen = 0; c.NLS = c.G = 0;
+  c.pipeline = c.shade = c.shadows = c.tune = c.throughput = c.tunable = c.guard = false; c.max_gen = 0; c.NLS = c.G = 0;
   std::memset(&c.stats, 0, sizeof c.stats);
   span_begin(s, false);
   return RTX_OK;
 }
 // ... and ends here: closes the span; the call is now in flight.
 static void stats_enqueue_end(rtx_scene* s) {
+  if (cur_call(s).guard) (void)hipMemcpyAsync(cur_call(s).hg, ws(s).w_guard.p, 12, hipMemcpyDeviceToHost, ws(s).stream);
   span_end(s, false);
   cur_call(s).pending = true;
 }
@@ -878,6 +892,37 @@ static uint32_t trace_blocks(rtx_scene* s, uint64_t quads) {
   if (upw > 1 && cur_call(s).throughput) g = std::max<uint64_t>((g + upw - 1) / upw, std::min<uint64_t>(g, (uint64_t)s->ncu));
   return (uint32_t)std::min<uint64_t>(g, (uint64_t)trace_grid(s));
 }
+// Domain guard + verification behind a closest-hit launch of caller or camera rays (rtx_kernels.h, guard_and_verify).
+static uint32_t verify_stride(const rtx_scene* s, uint64_t n) {
+  return (s->flags & RTX_FLAG_VERIFY) ? (uint32_t)std::max<uint64_t>(1, n / 2048) : 0u;
+}
+static int guard_begin(rtx_scene* s) {
+  rtx_scene::Call& c = cur_call(s);
+  if (!c.guard) { HIP_TRY(hipMemsetAsync(ws(s).w_guard.p, 0, 16, ws(s).stream)); c.guard = true; }
+  return RTX_OK;
+}
+static int guard_queue(rtx_scene* s, const float4* rays, const uint32_t* count, uint64_t n, uint32_t bounded, uint2* hits) {
+  if (s->dev.ntris == 0 && s->dev.nspheres == 0) return RTX_OK;
+  if (int rc = guard_begin(s)) return rc;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(n, 1), (uint64_t)s->ncu * 8);
+  hipLaunchKernelGGL(k_guard_queue, dim3(grid), dim3(kBlock), 0, ws(s).stream, s->dev, rays, count, 1u, bounded, s->domain, verify_stride(s, n), hits,
+                     ws(s).w_guard.as<uint32_t>());
+  return RTX_OK;
+}
+static int guard_camera(rtx_scene* s, const DevCamera& C, uint32_t nslots, uint2* hits) {
+  const bool far = std::max(std::fabs(C.origin[0]), std::max(std::fabs(C.origin[1]), std::fabs(C.origin[2]))) > s->domain;
+  const uint32_t vs = verify_stride(s, nslots);
+  if ((!far && vs == 0) || s->dev.ntris == 0) return RTX_OK;
+  // every pixel of a camera beyond the domain is a brute-force scan: fine for the reference's own scenes, not for millions of triangles
+  if (far && (double)nslots * (double)s->dev.ntris > 7e10)
+    return fail(RTX_ELIMIT, "the camera is farther than %g from the origin, beyond what this mesh's culling boxes are padded for, and %u pixels x %u "
+                            "triangles is too much to answer by brute force: move the camera closer or render a smaller rectangle", (double)s->domain,
+                nslots, s->dev.ntris);
+  if (int rc = guard_begin(s)) return rc;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(nslots, (uint64_t)s->ncu * 8);
+  hipLaunchKernelGGL(k_guard_camera, dim3(grid), dim3(kBlock), 0, ws(s).stream, s->dev, C, nslots, s->domain, vs, hits, ws(s).w_guard.as<uint32_t>());
+  return RTX_OK;
+}
 static int launch_trace_camera(rtx_scene* s, const DevCamera& C, uint32_t tiles, uint2* hits) {
   const uint32_t grid = trace_blocks(s, tiles);
   const uint32_t grid_r = std::min<uint32_t>(grid, (uint32_t)s->ncu * RTX_BLOCKS_REFILL);
@@ -917,7 +962,7 @@ static int trace_rays_dev(rtx_scene* s, const float* d_o, const float* d_d, uint
   span_begin(s, true);
   if (int rc = launch_trace_queue(s, ws(s).w_rays[0].as<float4>(), ws(s).w_counters.as<uint32_t>(), 1u, n, ws(s).w_hits[0].as<uint2>())) return rc;
   span_end(s, true);
-  return RTX_OK;
+  return guard_queue(s, ws(s).w_rays[0].as<float4>(), ws(s).w_counters.as<uint32_t>(), n, 0u, ws(s).w_hits[0].as<uint2>());
 }
 
 extern "C" int rtx_trace_closest_dev(rtx_scene* s, const float* o, const float* d, uint32_t n, float* t, int32_t* face) {
@@ -987,6 +1032,7 @@ extern "C" int rtx_trace_visible(rtx_scene* s, const float* light, const float* 
   span_begin(s, true);
   if (int rc = launch_trace_queue(s, ws(s).w_rays[0].as<float4>(), ws(s).w_counters.as<uint32_t>(), 1u, n, ws(s).w_hits[0].as<uint2>(), true)) return rc;
   span_end(s, true);
+  if (int rc = guard_queue(s, ws(s).w_rays[0].as<float4>(), ws(s).w_counters.as<uint32_t>(), n, 1u, ws(s).w_hits[0].as<uint2>())) return rc;
   hipLaunchKernelGGL(k_visible, dim3((n + 255) / 256), dim3(256), 0, ws(s).stream, s->dev, s->w_io[0].as<float>(),
                      ws(s).w_rays[0].as<float4>(), ws(s).w_hits[0].as<uint2>(), n, s->w_io[2].as<unsigned char>(), s->w_io[3].as<int>());
   cur_call(s).stats.rays_shadow = n;
@@ -1202,6 +1248,8 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
     if (int rc = launch_trace_queue(s, ws(s).w_rays[0].as<float4>(), n0_dev, 1u, pr.n0, ws(s).w_hits[0].as<uint2>())) return rc;
   }
   span_end(s, true);
+  if (pr.camera) { if (int rc = guard_camera(s, pr.C, pr.n0, ws(s).w_hits[0].as<uint2>())) return rc; }
+  else if (int rc = guard_queue(s, ws(s).w_rays[0].as<float4>(), n0_dev, pr.n0, 0u, ws(s).w_hits[0].as<uint2>())) return rc;
 
   const float th_gi = G ? (float)(M_PI * 2 / (double)G) : 0.0f;      // Ray::resendRay: float theta = M_PI * 2 / n
   const float th_sl = (float)(M_PI * 2 / 4);                          // Shader::getNPointsOnCircle with n = 4
@@ -1543,7 +1591,7 @@ extern "C" int rtx_scene_clone(const rtx_scene* src, rtx_scene** out) {
   s->leaf_faces = src->leaf_faces; s->have_leaves = src->have_leaves; s->flags = src->flags;
   s->built = src->built; s->h_tri_leaf = src->h_tri_leaf; s->h_face_nm = src->h_face_nm; s->h_tri_face = src->h_tri_face;
   std::memcpy(s->root_lo, src->root_lo, sizeof s->root_lo); std::memcpy(s->root_hi, src->root_hi, sizeof s->root_hi);
-  s->nwild = src->nwild; s->bvh = src->bvh; s->info = src->info;
+  s->nwild = src->nwild; s->bvh = src->bvh; s->info = src->info; s->domain = src->domain;
   *out = s;
   return RTX_OK;
 }
@@ -1685,6 +1733,10 @@ extern "C" int rtx_trace_closest_noalloc(rtx_scene* s, const float* o, const flo
   else
     hipLaunchKernelGGL(k_trace_queue<true>, dim3(grid), dim3(kBlock), 0, st, s->dev, rays, count, 1u, 0u, grab_size(),
                        (s->flags & RTX_FLAG_SCHED_SPLIT) ? kTriMinSplit : 1u, ovf, hits);
+  // the domain guard as in rtx_trace_closest_dev (its counters, never read back, live in the scratch array too)
+  if (s->dev.ntris != 0 || s->dev.nspheres != 0)
+    hipLaunchKernelGGL(k_guard_queue, dim3(std::min<uint32_t>(n, kNoAllocBlocks * 8u)), dim3(kBlock), 0, st, s->dev, (const float4*)rays, (const uint32_t*)count, 1u, 0u,
+                       s->domain, 0u, hits, count + 16);
   hipLaunchKernelGGL(k_unpack_hits, dim3(blocks), dim3(256), 0, st, s->dev, rays, hits, n, t, face, (float*)nullptr, (float*)nullptr,
                      (int*)nullptr);
   HIP_TRY(hipStreamSynchronize(st));

@@ -675,6 +675,89 @@ __device__ __forceinline__ void trace_wave_groups(const DevScene& S, const TopLe
 }
 
 
+// ---------------------------------------------------------------- brute force (domain guard, verification)
+// The hierarchy's boxes are padded for the rounding of o + t d up to origins ~30 scene extents away (rtx.hip,
+// rtx_scene_build).  A ray from beyond that is answered the way the reference answers every ray -- all triangles,
+// no boxes -- by a whole block: 256 threads share the triangles of one ray and reduce to the (t, face) minimum.
+// The same routine re-checks sampled rays of any launch when the scene asks for verification.
+__device__ __forceinline__ bool out_of_domain(V3 o, float domain) {
+  return fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) > domain;       // (false for NaN: such a ray hits nothing anyway)
+}
+__device__ __forceinline__ bool hit_before(const Hit& a, const Hit& b) {   // does a win over b in getIntersections' reduction?
+  if (a.id == -1) return false;
+  if (b.id == -1) return true;
+  if (a.t != b.t) return a.t < b.t;
+  if ((a.id < 0) != (b.id < 0)) return a.id < 0;                            // a sphere found first keeps an equal t (strict <)
+  return a.id >= 0 ? a.id < b.id : a.id > b.id;                             // lowest face id / first sphere
+}
+// All threads of the block call this with the same ray; returns the closest hit over spheres + gate + every triangle.
+__device__ __forceinline__ Hit brute_closest(const DevScene& S, V3 o, V3 d1, float tmax, Hit* red) {
+  Hit best; best.t = tmax; best.id = -1;
+  for (uint32_t i = 0; i < S.nspheres; ++i) {
+    const float t = ref_sphere_t(o, d1, S.spheres[i]);
+    if (t != INFINITY && t < best.t) { best.t = t; best.id = -2 - (int)i; }
+  }
+  if (S.ntris != 0) {
+    const V3 d = normalized(d1);
+    if ((S.flags & 1u) || ref_box_t(o, d, S.root_lo, S.root_hi) != INFINITY)
+      for (uint32_t k = threadIdx.x; k < S.ntris; k += kBlock) test_triangle(S, k, o, d, &best);
+  }
+  red[threadIdx.x] = best;
+  __syncthreads();
+  for (int off = kBlock / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off && hit_before(red[threadIdx.x + off], red[threadIdx.x])) red[threadIdx.x] = red[threadIdx.x + off];
+    __syncthreads();
+  }
+  const Hit r = red[0];
+  __syncthreads();
+  return r;
+}
+// ctr: [0] rays answered by brute force (out of the domain), [1] rays re-checked, [2] of which differed
+template <class Source>
+__device__ __forceinline__ void guard_and_verify(const DevScene& S, const Source& src, uint32_t n, float domain, uint32_t verify_stride,
+                                                 uint2* hits, uint32_t* ctr) {
+  __shared__ Hit red[kBlock];
+  const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+  const uint32_t beg = blockIdx.x * per < n ? blockIdx.x * per : n, end = beg + per < n ? beg + per : n;
+  for (uint32_t j = beg; j < end; ++j) {
+    V3 o, d1; uint32_t slot; float tmax;
+    if (!src.get(j, &o, &d1, &slot, &tmax)) continue;
+    const bool far = out_of_domain(o, domain);
+    const bool check = verify_stride != 0 && j % verify_stride == 0;
+    if (!far && !check) continue;
+    const Hit h = brute_closest(S, o, d1, tmax, red);
+    if (threadIdx.x == 0) {
+      const uint2 want = make_uint2(__float_as_uint(h.id == -1 ? INFINITY : h.t), (uint32_t)h.id);
+      if (check && !far) {
+        const uint2 got = hits[slot];
+        atomicAdd(&ctr[1], 1u);
+        if (got.x != want.x || got.y != want.y) atomicAdd(&ctr[2], 1u);
+      }
+      if (far) { hits[slot] = want; atomicAdd(&ctr[0], 1u); }
+    }
+  }
+}
+struct PlainCameraSource {          // the pixels of the rectangle in slot order (no 16x16 block mapping)
+  DevCamera C;
+  __device__ __forceinline__ bool get(uint32_t j, V3* o, V3* d1, uint32_t* slot, float* tmax) const {
+    int x, y;
+    *tmax = INFINITY; *slot = j;
+    if (!slot_pixel(C, j, &x, &y)) return false;
+    camera_ray(C, x, y, o, d1);
+    return true;
+  }
+};
+__global__ __launch_bounds__(kBlock) void k_guard_camera(DevScene S, DevCamera C, uint32_t nslots, float domain, uint32_t verify_stride, uint2* hits,
+                                                       uint32_t* ctr) {
+  PlainCameraSource src; src.C = C;
+  guard_and_verify(S, src, nslots, domain, verify_stride, hits, ctr);
+}
+__global__ __launch_bounds__(kBlock) void k_guard_queue(DevScene S, const float4* rays, const uint32_t* count, uint32_t stride, uint32_t bounded,
+                                                      float domain, uint32_t verify_stride, uint2* hits, uint32_t* ctr) {
+  QueueSource src; src.rays = rays; src.bounded = bounded; src.anyhit = 0u;
+  guard_and_verify(S, src, *count * stride, domain, verify_stride, hits, ctr);
+}
+
 // Camera rays of a pixel rectangle.  Ray index j = (16x16 pixel block, thread): consecutive
 // indices walk 8x8 pixel sub-tiles, so the 64 rays of a chunk are coherent.  Writes {t, id}.
 template <bool kRefill>
