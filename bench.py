@@ -125,16 +125,18 @@ def launch_ranks(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default=WORKLOADS[0], choices=WORKLOADS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=6144, help="primary rays in the cpu_baseline sample")
     ap.add_argument("--roofline-stride", type=int, default=16, help="every k-th pixel feeds the byte count")
     ap.add_argument("--no-scaling-proxy", action="store_true")
-    ap.add_argument("--inflight", type=int, default=3, choices=[1, 2, 3, 4, 5, 6, 7, 8],
-                    help="frames in flight (rtx_render_*_enqueue): they run side by side on the GPU, each on its own streams")
+    ap.add_argument("--inflight", type=int, default=2, choices=[1, 2, 3, 4],
+                    help="render calls in flight (rtx_render_*_enqueue): they run side by side on the GPU, each on its own streams")
+    ap.add_argument("--batch", type=int, default=8,
+                    help="frames per render call (rtx_render_tiles_batch_dev_enqueue, 1-16): one set of launches traces them all")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -181,41 +183,47 @@ def main():
     kmax = tiles.max_local_tiles(W, H, TILE, world)
     # one rank owns the whole frame: render it row-major in place, nothing to gather or reassemble
     npix_local = kmax * TILE * TILE if world > 1 else W * H
+    pipelined = len(cams) == 1
+    B = max(1, min(args.batch, api.MAX_BATCH)) if pipelined else 1
     # Three sets of output buffers: the render of frame k+1 (librtx's own stream) overlaps the gather
     # and reassembly of frame k (torch's streams); a set is reused only after the torch work that
     # read it has finished (event per set).
     NSETS = max(3, args.inflight + 2)
     sets = []
     for _ in range(NSETS):
-        b = {"rgb": torch.zeros((npix_local, 3), dtype=torch.float32, device=dev),
-             "face": torch.full((npix_local, 1), -1, dtype=torch.int32, device=dev),
+        b = {"rgb": torch.zeros((B * npix_local, 3), dtype=torch.float32, device=dev),
+             "face": torch.full((B * npix_local, 1), -1, dtype=torch.int32, device=dev),
              "free": torch.cuda.Event()}
         b["acc"] = torch.zeros_like(b["rgb"]) if len(cams) > 1 else None
         if world > 1 and rank == 0:
-            b["img"] = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+            b["img"] = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
         if world > 1 and rank == 0 and not rehearse:
-            b["g_rgb"] = torch.empty((world, npix_local, 3), dtype=torch.float32, device=dev)
+            b["g_rgb"] = torch.empty((world, B * npix_local, 3), dtype=torch.float32, device=dev)
         b["free"].record()
         sets.append(b)
     state = {"k": 0}
 
-    def exchange(b, out, face):
-        """The finished local pixels -> the frame on rank 0 (None elsewhere)."""
+    def exchange(b, out, face, nf=1):
+        """The finished local pixels of nf frames -> the last of those frames on rank 0 (None elsewhere)."""
         if world == 1:
-            return (out.view(H, W, 3), face.view(H, W, 1))
-        # several ranks: the frame that travels is the colour image (what raytraceScene produces); hit ids
-        # stay where they were computed (12 instead of 16 bytes per pixel into rank 0 and through assemble)
+            return (out.view(-1, H, W, 3)[nf - 1], face.view(-1, H, W, 1)[nf - 1])
+        # several ranks: the frames that travel are the colour images (what raytraceScene produces); hit ids
+        # stay where they were computed (12 instead of 16 bytes per pixel into rank 0 and through assemble).
+        # One gather per render call: all nf frames of the batch at once.
+        out = out[: nf * npix_local]
         if rehearse:
             g_rgb = tiles.gather_to_root(out.cpu(), world, rank, dist)
             if rank == 0:
                 g_rgb = g_rgb.to(dev)
         else:
-            g_rgb = tiles.gather_to_root(out, world, rank, dist, b.get("g_rgb"))
+            g_rgb = tiles.gather_to_root(out, world, rank, dist, b["g_rgb"][:, : nf * npix_local] if rank == 0 else None)
         if rank == 0:
-            # one pass back to row-major (rtx_tiles_assemble_dev on torch's stream; tiles.assemble is its torch twin)
-            api.tiles_assemble_dev(g_rgb.data_ptr(), world, g_rgb.shape[1], rect, TILE, 3, b["img"].data_ptr(),
-                                   torch.cuda.current_stream().cuda_stream)
-            return (b["img"], None)
+            # one pass per frame back to row-major (rtx_tiles_assemble_dev on torch's stream; tiles.assemble is its torch twin)
+            stride = g_rgb.stride(0) // 3
+            for f in range(nf):
+                api.tiles_assemble_dev(g_rgb.data_ptr() + f * npix_local * 12, world, stride, rect, TILE, 3, b["img"][f].data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream)
+            return (b["img"][nf - 1], None)
         return None
 
     def frame():
@@ -253,38 +261,39 @@ def main():
     # One sample per pixel: frames go through the enqueue / finish entry points, frame k+1 queued before
     # frame k is waited for (and, with several ranks, gathered), so the GPU does not idle while the host
     # finishes a frame.  Several samples per pixel are accumulated by torch between passes: synchronous.
-    pipelined = len(cams) == 1
-
-    def frame_enqueue():
+    # Frames of a sequence go to the library B at a time (one camera per frame -- the same one here, the library
+    # does not know that): one set of launches traces and shades the rank's tiles of all B frames.
+    def batch_enqueue(nf):
         b = sets[state["k"] % NSETS]
         state["k"] += 1
         b["free"].synchronize()
-        if world > 1:
-            scene.render_tiles_dev_enqueue(cams[0], opts, rect, TILE, rank, world, b["rgb"].data_ptr(), None, b["face"].data_ptr())
-        else:
-            scene.render_dev_enqueue(cams[0], opts, rect, b["rgb"].data_ptr(), None, b["face"].data_ptr())
+        b["nf"] = nf
+        scene.render_tiles_batch_dev([cams[0]] * nf, opts, rect, TILE if world > 1 else 0, rank if world > 1 else 0, world,
+                                     b["rgb"].data_ptr(), None, b["face"].data_ptr(), enqueue=True)
         return b
 
-    def frame_finish(b):
+    def batch_finish(b):
         st = scene.render_finish()
         rays = [st.rays_primary, st.rays_shadow, st.rays_reflection]
         ms = [st.ms_trace_camera, st.ms_trace - st.ms_trace_camera, st.ms_total]
-        img = exchange(b, b["rgb"], b["face"])
+        img = exchange(b, b["rgb"], b["face"], b["nf"])
         b["free"].record()
         return rays, ms, img
 
     def frames(n):
-        """n frames; returns the per-frame (rays, ms, img) tuples."""
+        """n frames; returns (rays, ms, img) per render call (per frame, or per batch of up to B frames)."""
         out = []
         if not pipelined:
             return [frame() for _ in range(n)]
         flying = []
-        for _ in range(n):
-            flying.append(frame_enqueue())
+        left = n
+        while left > 0:
+            flying.append(batch_enqueue(min(B, left)))
+            left -= min(B, left)
             if len(flying) >= args.inflight:
-                out.append(frame_finish(flying.pop(0)))
+                out.append(batch_finish(flying.pop(0)))
         while flying:
-            out.append(frame_finish(flying.pop(0)))
+            out.append(batch_finish(flying.pop(0)))
         return out
 
     def sync():
@@ -295,7 +304,7 @@ def main():
 
     # setup, not steps: the library times its wave schedulers on its first seven render calls of a
     # scene and keeps the fastest per launch kind; let that settle before the warmup / timed steps
-    frames(7)
+    frames(7 * B)
     frames(args.warmup)
     sync()
     t0 = time.perf_counter()
@@ -328,7 +337,7 @@ def main():
                 ms_iso += [st.ms_trace_camera, st.ms_trace - st.ms_trace_camera, st.ms_total]
         ms_iso /= args.steps
     # pixels whose primary ray hit geometry, from the hit ids of the last frame on every rank
-    last = sets[(state["k"] - 1) % NSETS]["face"]
+    last = sets[(state["k"] - 1) % NSETS]["face"][:npix_local]
     nhit = torch.tensor([float((last >= 0).sum().item())], dtype=torch.float64, device="cpu" if rehearse else dev)
     if dist is not None:
         dist.all_reduce(nhit)
@@ -345,7 +354,8 @@ def main():
                        "triangles_outside_bvh": int(info.nwild),
                        "image": [W, H], "lights": len(wl["lights"]), "spp": wl["spp"], "max_bounces": wl["opts"][0],
                        "tile": TILE, "partition": (("image tiles round-robin over %d ranks, scene replicated, RGB gathered to rank 0" % world) if world > 1
-                                     else "one rank renders the whole frame row-major") + (("; %d frames in flight (rtx_render_*_enqueue / rtx_render_finish)" % args.inflight) if pipelined else ""),
+                                     else "one rank renders the whole frame row-major") + (("; %d frames per render call (rtx_render_tiles_batch_dev_enqueue), %d calls in flight" % (B, args.inflight)) if pipelined else ""),
+                       "frames_per_call": B, "calls_in_flight": args.inflight if pipelined else 1,
                        "rays_per_frame": {"primary": int(agg[0].item() / args.steps), "shadow": int(agg[1].item() / args.steps),
                                           "reflection": int(agg[2].item() / args.steps)},
                        "pixels_hitting_geometry": hits,
@@ -363,7 +373,7 @@ def main():
             result["config"]["rehearsal_equals_full_frame"] = bool(
                 hits == int((f_face >= 0).sum().item()) and torch.equal(img[0].reshape(-1, 3).view(torch.int32), f_rgb.view(torch.int32)))
     if rank == 0 and world == 1 and not args.no_scaling_proxy:
-        result["scaling_proxy"] = scaling_proxy(scene, cams[0], opts, rect, W, H, torch, dev, tiles, max(5, args.steps), args.inflight)
+        result["scaling_proxy"] = scaling_proxy(scene, cams[0], opts, rect, W, H, torch, dev, tiles, max(5, args.steps), args.inflight, B)
     if rank == 0 and world == 1 and not args.no_roofline:
         result["config"]["kernel_ms_per_frame_one_at_a_time"] = {"trace_camera": ms_iso[0], "trace_queue": ms_iso[1], "all_kernels": ms_iso[2]}
         result["roofline"] = roofline(args, wl, scene, info, ms_iso, rays_tot / args.steps)
@@ -382,29 +392,32 @@ def main():
     scene.close()
 
 
-def scaling_proxy(scene, cam, opts, rect, W, H, torch, dev, tiles, steps, inflight=3):
+def scaling_proxy(scene, cam, opts, rect, W, H, torch, dev, tiles, steps, inflight=2, batch=1):
     """Strong scaling rehearsed on one GPU: the share of rank 0 of N (rtx_render_tiles_dev, part 0 of N, the
-    call every rank of an N-GPU run makes) timed alone, two frames in flight like the bench loop.  With perfect
+    call every rank of an N-GPU run makes) timed alone, in batches and with calls in flight like the bench loop.  With perfect
     scaling part 0 of N costs 1/N of part 0 of 1; the ratio is the render-side bound on the N-GPU speed-up
     (the RGB gather and reassembly on rank 0 come on top and overlap the next frame's render)."""
     ms = {}
     for nparts in (1, 2, 4, 8):
         kmax = tiles.max_local_tiles(W, H, TILE, nparts)
-        rgb = torch.zeros((kmax * TILE * TILE, 3), dtype=torch.float32, device=dev)
-        face = torch.full((kmax * TILE * TILE, 1), -1, dtype=torch.int32, device=dev)
+        rgb = torch.zeros((batch * kmax * TILE * TILE, 3), dtype=torch.float32, device=dev)
+        face = torch.full((batch * kmax * TILE * TILE, 1), -1, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
 
         def run(n):
             flying = 0
-            for k in range(n):
-                scene.render_tiles_dev_enqueue(cam, opts, rect, TILE, 0, nparts, rgb.data_ptr(), None, face.data_ptr())
+            left = n
+            while left > 0:
+                nf = min(batch, left)
+                left -= nf
+                scene.render_tiles_batch_dev([cam] * nf, opts, rect, TILE, 0, nparts, rgb.data_ptr(), None, face.data_ptr(), enqueue=True)
                 flying += 1
                 if flying >= inflight:
                     scene.render_finish()
                     flying -= 1
             for _ in range(flying):
                 scene.render_finish()
-        run(8)                                   # the scheduler tuner starts over when the ray count changes 2x
+        run(8 * batch)                           # the scheduler tuner starts over when the ray count changes 2x
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run(steps)

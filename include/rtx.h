@@ -284,6 +284,23 @@ int rtx_render_tiles_dev_enqueue(rtx_scene*, const rtx_camera*, const rtx_option
                                  int32_t tile_size, int32_t part, int32_t nparts,
                                  float* rgb, float* t, int32_t* face_id);
 
+/* A batch of frames in one call: nframes (1 .. RTX_MAX_BATCH) cameras over the same rectangle and tile partition,
+ * traced and shaded by ONE set of kernel launches; frame f's pixels land at rgb + 3 f P, t + f P, face_id + f P with
+ * P = rtx_tiles_count(rect, tile_size, part, nparts) * tile_size^2 -- or, with tile_size 0 (part 0 of 1), the whole
+ * rectangle row-major and P = its pixels.  Every frame's values are those of rtx_render_tiles_dev (rtx_render_dev)
+ * with that camera, bit for bit.  For the ranks of an N-GPU run: a rank's share of one frame gives its persistent
+ * traversal kernels too few rays to run at full rate (1/8 of the 4K soup frame: 0.37 ms instead of 0.23 ms), its
+ * share of N frames of an animation gives them as many as one whole frame.  The enqueue form is finished by
+ * rtx_render_finish like the others; rtx_stats counts the rays of all frames of the batch.
+ * No counterpart in the reference (raytraceScene renders one camera, src/flyscene.cpp:395-468). */
+#define RTX_MAX_BATCH 16
+int rtx_render_tiles_batch_dev(rtx_scene*, const rtx_camera* cams, int32_t nframes, const rtx_options*, rtx_rect rect,
+                               int32_t tile_size, int32_t part, int32_t nparts,
+                               float* rgb, float* t, int32_t* face_id);
+int rtx_render_tiles_batch_dev_enqueue(rtx_scene*, const rtx_camera* cams, int32_t nframes, const rtx_options*, rtx_rect rect,
+                                       int32_t tile_size, int32_t part, int32_t nparts,
+                                       float* rgb, float* t, int32_t* face_id);
+
 /* The inverse of that layout, for the rank that collects the parts: `parts` holds the compact buffers of
  * parts 0 .. nparts-1 one after the other, part_stride_pixels apart (>= rtx_tiles_count(rect, tile_size, 0,
  * nparts) * tile_size^2), words_per_pixel 32-bit words per pixel (3 for rgb, 1 for t or face_id);

@@ -50,12 +50,13 @@ SYMBOLS = ["rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_
            "rtx_scene_add_material", "rtx_scene_set_spheres", "rtx_scene_set_lights", "rtx_scene_build", "rtx_scene_commit",
            "rtx_scene_get_tris",
            "rtx_scene_get_info", "rtx_scene_get_bvh", "rtx_trace_closest", "rtx_trace_closest_dev",
-           "rtx_trace_visible", "rtx_render", "rtx_render_dev", "rtx_render_dev_enqueue", "rtx_render_finish", "rtx_tiles_count", "rtx_render_tiles_dev", "rtx_render_tiles_dev_enqueue", "rtx_tiles_assemble_dev",
+           "rtx_trace_visible", "rtx_render", "rtx_render_dev", "rtx_render_dev_enqueue", "rtx_render_finish", "rtx_tiles_count", "rtx_render_tiles_dev", "rtx_render_tiles_dev_enqueue", "rtx_render_tiles_batch_dev", "rtx_render_tiles_batch_dev_enqueue", "rtx_tiles_assemble_dev",
            "rtx_get_stats", "rtx_scene_build_reference_leafboxes", "rtx_scene_set_leafboxes",
            "rtx_scene_get_leafboxes", "rtx_intersect_box", "rtx_trace_shade", "rtx_camera_points", "rtx_scene_set_flags",
            "rtx_scene_get_packed_bvh", "rtx_debug_hit", "rtx_trace_closest_noalloc", "rtx_scene_clone", "rtx_render_multi",
            "rtx_render_multi_dev", "rtx_intersect_primitive", "rtx_trace_gi"]
 
+MAX_BATCH = 16
 NOALLOC_MAX_RAYS = 65536
 FLAG_NO_ROOT_GATE, FLAG_SCHED_REFILL, FLAG_SCHED_GROUPS, FLAG_SCHED_SPLIT, FLAG_VERIFY = 1, 2, 4, 8, 16
 
@@ -133,6 +134,9 @@ def lib():
                                            C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rtx_render_tiles_dev_enqueue.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Options), Rect, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        for fn in (L.rtx_render_tiles_batch_dev, L.rtx_render_tiles_batch_dev_enqueue):
+            fn.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int32, C.POINTER(Options), Rect, C.c_int32, C.c_int32, C.c_int32,
+                           C.c_void_p, C.c_void_p, C.c_void_p]
         L.rtx_tiles_assemble_dev.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, Rect, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -381,6 +385,13 @@ class Scene:
         x0, y0, x1, y1 = rect
         _check(lib().rtx_render_tiles_dev_enqueue(self.h, C.byref(cam), C.byref(opts), Rect(x0, y0, x1, y1), tile_size, part,
                                                   nparts, rgb_ptr, t_ptr, face_ptr))
+
+    def render_tiles_batch_dev(self, cams, opts, rect, tile_size, part, nparts, rgb_ptr, t_ptr, face_ptr, enqueue=False):
+        """rtx_render_tiles_batch_dev(_enqueue): len(cams) frames in one set of launches; frame f's pixels follow frame f-1's."""
+        x0, y0, x1, y1 = rect
+        arr = (Camera * len(cams))(*cams)
+        fn = lib().rtx_render_tiles_batch_dev_enqueue if enqueue else lib().rtx_render_tiles_batch_dev
+        _check(fn(self.h, arr, len(cams), C.byref(opts), Rect(x0, y0, x1, y1), tile_size, part, nparts, rgb_ptr, t_ptr, face_ptr))
 
     def stats(self):
         s = Stats()

@@ -104,15 +104,16 @@ struct rtx_scene {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;     // bounce launches that overlap the shadow launch of the same generation (run_pipeline)
     DevBuf w_cam_tab;                  // camera tables (k_camera_tables)
-    DevCamera cam_tab_of{};            // the camera w_cam_tab currently holds the tables of (valid: cam_tab_ok)
+    std::vector<DevCamera> cam_tab_of; // the cameras w_cam_tab (and w_frames) currently hold the tables of (valid: cam_tab_ok)
     bool cam_tab_ok = false;
+    DevBuf w_frames;                   // per-frame inverse views and centres of a batch (rtx_render_tiles_batch_dev)
     DevBuf w_stack_ovf;                // global overflow columns of the per-lane traversal stacks
     DevBuf w_stack_ovf2;               // ... of the launches on stream2 (they run beside launches on `stream`)
     DevBuf w_rays[2], w_hits[3], w_parents, w_shadow_rays, w_shadow_hits, w_gi_rays, w_gi_hits, w_counters;
     DevBuf w_guard;                    // counters of the domain guard / verification kernels
     DevBuf w_acc, w_acc_flag;          // fixed-point pixel sums of ray-tree calls (reflection + refraction)
     template <class F> void for_each_buf(F f) {
-      f(w_cam_tab); f(w_stack_ovf); f(w_stack_ovf2); f(w_rays[0]); f(w_rays[1]); f(w_hits[0]); f(w_hits[1]); f(w_hits[2]);
+      f(w_cam_tab); f(w_frames); f(w_stack_ovf); f(w_stack_ovf2); f(w_rays[0]); f(w_rays[1]); f(w_hits[0]); f(w_hits[1]); f(w_hits[2]);
       f(w_parents); f(w_shadow_rays); f(w_shadow_hits); f(w_gi_rays); f(w_gi_hits); f(w_counters); f(w_acc); f(w_acc_flag); f(w_guard);
     }
   };
@@ -909,8 +910,12 @@ static int guard_queue(rtx_scene* s, const float4* rays, const uint32_t* count, 
                      ws(s).w_guard.as<uint32_t>());
   return RTX_OK;
 }
-static int guard_camera(rtx_scene* s, const DevCamera& C, uint32_t nslots, uint2* hits) {
-  const bool far = std::max(std::fabs(C.origin[0]), std::max(std::fabs(C.origin[1]), std::fabs(C.origin[2]))) > s->domain;
+static int guard_camera(rtx_scene* s, const DevCamera& C, const DevCamera* cams, uint32_t nframes, uint32_t nslots, uint2* hits) {
+  bool far = false;     // C: frame 0 with the device pointers set; cams: the frames of the batch (host copies)
+  for (uint32_t f = 0; f < nframes; ++f) {
+    const float* o = cams ? cams[f].origin : C.origin;
+    far = far || std::max(std::fabs(o[0]), std::max(std::fabs(o[1]), std::fabs(o[2]))) > s->domain;
+  }
   const uint32_t vs = verify_stride(s, nslots);
   if ((!far && vs == 0) || s->dev.ntris == 0) return RTX_OK;
   // every pixel of a camera beyond the domain is a brute-force scan: fine for the reference's own scenes, not for millions of triangles
@@ -1066,11 +1071,12 @@ static int make_camera(const rtx_camera* cam, rtx_rect r, DevCamera* C) {
   C->scale = scale;
   C->sub[0] = cam->subpixel[0]; C->sub[1] = cam->subpixel[1];
   C->x0 = r.x0; C->y0 = r.y0; C->w = r.x1 - r.x0; C->h = r.y1 - r.y0;
-  C->ts = 0; C->part = 0; C->nparts = 1; C->tiles_x = 0; C->ntiles_local = 0; C->pad_ = 0; C->tab = nullptr;
+  C->ts = 0; C->part = 0; C->nparts = 1; C->tiles_x = 0; C->ntiles_local = 0; C->tab = nullptr;
+  C->nframes = 1; C->frame_slots = 0; C->frame_blocks = 0; C->frames = nullptr;
   return RTX_OK;
 }
 
-static int render_impl(rtx_scene* s, const DevCamera& C, uint32_t npix, uint32_t nblocks, const rtx_options* opt,
+static int render_impl(rtx_scene* s, const DevCamera* cams, uint32_t nframes, uint32_t npix, uint32_t nblocks, const rtx_options* opt,
                        float* rgb, float* t, int32_t* face, bool wait = true);
 static int check_render_args(rtx_scene* s, const rtx_camera* cam, const rtx_options* opt, const float* rgb);
 
@@ -1093,7 +1099,7 @@ extern "C" int rtx_render_dev(rtx_scene* s, const rtx_camera* cam, const rtx_opt
   if (int rc = make_camera(cam, rect, &C)) return rc;
   const uint32_t npix = (uint32_t)C.w * (uint32_t)C.h;
   const uint32_t tiles = (uint32_t)((C.w + 15) / 16) * (uint32_t)((C.h + 15) / 16);
-  return render_impl(s, C, npix, tiles, opt, rgb, t, face);
+  return render_impl(s, &C, 1, npix, tiles, opt, rgb, t, face);
 }
 
 // rtx_render_dev without the wait at the end: the call's kernels are queued on the scene's stream and
@@ -1106,7 +1112,7 @@ extern "C" int rtx_render_dev_enqueue(rtx_scene* s, const rtx_camera* cam, const
   if (int rc = make_camera(cam, rect, &C)) return rc;
   const uint32_t npix = (uint32_t)C.w * (uint32_t)C.h;
   const uint32_t tiles = (uint32_t)((C.w + 15) / 16) * (uint32_t)((C.h + 15) / 16);
-  return render_impl(s, C, npix, tiles, opt, rgb, t, face, false);
+  return render_impl(s, &C, 1, npix, tiles, opt, rgb, t, face, false);
 }
 extern "C" int rtx_render_finish(rtx_scene* s, rtx_stats* out) {
   if (!s) return fail(RTX_EINVAL, "null scene");
@@ -1165,14 +1171,24 @@ extern "C" int rtx_tiles_assemble_dev(const void* parts, int32_t nparts, uint64_
   return RTX_OK;
 }
 
-static int render_tiles_impl(rtx_scene* s, const rtx_camera* cam, const rtx_options* opt, rtx_rect rect, int32_t tile_size,
-                             int32_t part, int32_t nparts, float* rgb, float* t, int32_t* face, bool wait) {
+static int render_tiles_impl(rtx_scene* s, const rtx_camera* cams, int32_t nframes, const rtx_options* opt, rtx_rect rect, int32_t tile_size,
+                             int32_t part, int32_t nparts, float* rgb, float* t, int32_t* face, bool wait, bool batch = false) {
   if (int rc = check_ready(s)) return rc;
-  if (int rc = check_render_args(s, cam, opt, rgb)) return rc;
-  const int nt = rtx_tiles_count(rect, tile_size, part, nparts);
-  if (nt < 0) return nt;
-  DevCamera C{};
-  if (int rc = make_camera(cam, rect, &C)) return rc;
+  if (nframes < 1 || nframes > kMaxBatch) return fail(RTX_ELIMIT, "a batch holds 1 to %d frames", kMaxBatch);
+  if (int rc = check_render_args(s, cams, opt, rgb)) return rc;
+  int nt;
+  if (tile_size == 0 && batch) {         // (batch entry points only) the whole rectangle, row-major
+    if (part != 0 || nparts != 1) return fail(RTX_EINVAL, "tile_size 0 renders the whole rectangle: part 0 of 1");
+    nt = 1;
+  } else {
+    nt = rtx_tiles_count(rect, tile_size, part, nparts);
+    if (nt < 0) return nt;
+  }
+  DevCamera C[kMaxBatch];
+  for (int32_t f = 0; f < nframes; ++f) {
+    C[f] = DevCamera{};
+    if (int rc = make_camera(&cams[f], rect, &C[f])) return rc;
+  }
   if (nt == 0) {                       // a part without tiles: an empty call, so that enqueue / finish still pair up
     if (wait) return RTX_OK;
     if (int rc = stats_begin(s)) return rc;
@@ -1180,26 +1196,52 @@ static int render_tiles_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opti
     cur_call(s).unreported = true;
     return RTX_OK;
   }
-  if ((int64_t)nt * tile_size * tile_size >= (1ll << 31)) return fail(RTX_ELIMIT, "too many pixels in this part");
-  C.ts = tile_size; C.part = part; C.nparts = nparts; C.tiles_x = (C.w + tile_size - 1) / tile_size;
-  C.ntiles_local = (uint32_t)nt;
-  const uint32_t npix = (uint32_t)nt * (uint32_t)(tile_size * tile_size);
-  const uint32_t nblocks = (uint32_t)nt * (uint32_t)((tile_size / 16) * (tile_size / 16));
-  return render_impl(s, C, npix, nblocks, opt, rgb, t, face, wait);
+  uint64_t npix, nblocks;
+  if (tile_size == 0) {
+    npix = (uint64_t)C[0].w * (uint64_t)C[0].h;
+    nblocks = (uint64_t)((C[0].w + 15) / 16) * (uint64_t)((C[0].h + 15) / 16);
+  } else {
+    npix = (uint64_t)nt * (uint64_t)(tile_size * tile_size);
+    nblocks = (uint64_t)nt * (uint64_t)((tile_size / 16) * (tile_size / 16));
+  }
+  if (npix * (uint64_t)nframes >= (1ull << 31) || nblocks * (uint64_t)nframes >= (1ull << 31) / 256)
+    return fail(RTX_ELIMIT, "too many pixels in this part");
+  for (int32_t f = 0; f < nframes; ++f) {
+    if (tile_size) {
+      C[f].ts = tile_size; C[f].part = part; C[f].nparts = nparts; C[f].tiles_x = (C[f].w + tile_size - 1) / tile_size;
+      C[f].ntiles_local = (uint32_t)nt;
+    }
+    C[f].nframes = (uint32_t)nframes; C[f].frame_slots = (uint32_t)npix; C[f].frame_blocks = (uint32_t)nblocks;
+  }
+  return render_impl(s, C, (uint32_t)nframes, (uint32_t)(npix * nframes), (uint32_t)(nblocks * nframes), opt, rgb, t, face, wait);
 }
 extern "C" int rtx_render_tiles_dev(rtx_scene* s, const rtx_camera* cam, const rtx_options* opt, rtx_rect rect,
                                     int32_t tile_size, int32_t part, int32_t nparts, float* rgb, float* t, int32_t* face) {
-  return render_tiles_impl(s, cam, opt, rect, tile_size, part, nparts, rgb, t, face, true);
+  return render_tiles_impl(s, cam, 1, opt, rect, tile_size, part, nparts, rgb, t, face, true);
 }
 extern "C" int rtx_render_tiles_dev_enqueue(rtx_scene* s, const rtx_camera* cam, const rtx_options* opt, rtx_rect rect,
                                             int32_t tile_size, int32_t part, int32_t nparts, float* rgb, float* t, int32_t* face) {
-  return render_tiles_impl(s, cam, opt, rect, tile_size, part, nparts, rgb, t, face, false);
+  return render_tiles_impl(s, cam, 1, opt, rect, tile_size, part, nparts, rgb, t, face, false);
+}
+// `nframes` cameras over one rectangle and tile partition in ONE set of launches: frame f's pixels land at
+// rgb + 3 f P, t + f P, face + f P with P = rtx_tiles_count(...) * tile_size^2 (tile_size 0: the whole rectangle
+// row-major, P = its pixels).  What a rank of an N-GPU run calls for its share of several frames of an animation:
+// the persistent traversal kernels then draw from nframes times as many rays per launch.
+extern "C" int rtx_render_tiles_batch_dev(rtx_scene* s, const rtx_camera* cams, int32_t nframes, const rtx_options* opt, rtx_rect rect,
+                                          int32_t tile_size, int32_t part, int32_t nparts, float* rgb, float* t, int32_t* face) {
+  if (!cams) return fail(RTX_EINVAL, "null camera/options");
+  return render_tiles_impl(s, cams, nframes, opt, rect, tile_size, part, nparts, rgb, t, face, true, true);
+}
+extern "C" int rtx_render_tiles_batch_dev_enqueue(rtx_scene* s, const rtx_camera* cams, int32_t nframes, const rtx_options* opt, rtx_rect rect,
+                                                  int32_t tile_size, int32_t part, int32_t nparts, float* rgb, float* t, int32_t* face) {
+  if (!cams) return fail(RTX_EINVAL, "null camera/options");
+  return render_tiles_impl(s, cams, nframes, opt, rect, tile_size, part, nparts, rgb, t, face, false, true);
 }
 
 // The generation loop of the ray queue.  Primary nodes are either the pixels of a camera
 // rectangle (implicit rays) or `n0` caller rays already converted to queue records in
 // w_rays[0] (Flyscene::traceRay(bounce0, ray, inside)).
-struct Primary { bool camera; DevCamera C; uint32_t n0, tiles; int bounce0; };
+struct Primary { bool camera; DevCamera C; uint32_t n0, tiles; int bounce0; const DevCamera* cams = nullptr; uint32_t nframes = 1; };
 
 static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt, float* rgb, float* t, int32_t* face) {
   const uint32_t NLS = s->dev.nlights + 5u * s->dev.nsl;
@@ -1248,7 +1290,7 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
     if (int rc = launch_trace_queue(s, ws(s).w_rays[0].as<float4>(), n0_dev, 1u, pr.n0, ws(s).w_hits[0].as<uint2>())) return rc;
   }
   span_end(s, true);
-  if (pr.camera) { if (int rc = guard_camera(s, pr.C, pr.n0, ws(s).w_hits[0].as<uint2>())) return rc; }
+  if (pr.camera) { if (int rc = guard_camera(s, pr.C, pr.cams, pr.nframes, pr.n0, ws(s).w_hits[0].as<uint2>())) return rc; }
   else if (int rc = guard_queue(s, ws(s).w_rays[0].as<float4>(), n0_dev, pr.n0, 0u, ws(s).w_hits[0].as<uint2>())) return rc;
 
   const float th_gi = G ? (float)(M_PI * 2 / (double)G) : 0.0f;      // Ray::resendRay: float theta = M_PI * 2 / n
@@ -1338,23 +1380,40 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
   return RTX_OK;
 }
 
-static int render_impl(rtx_scene* s, const DevCamera& C, uint32_t npix, uint32_t tiles, const rtx_options* opt,
+static int render_impl(rtx_scene* s, const DevCamera* cams, uint32_t nframes, uint32_t npix, uint32_t tiles, const rtx_options* opt,
                        float* rgb, float* t, int32_t* face, bool wait) {
   if (int rc = stats_begin(s)) return rc;
   cur_call(s).throughput = !wait && overlap_frames(s);
   cur_call(s).tunable = true;
-  const size_t tab_cap = ws(s).w_cam_tab.cap;
-  if (int rc = ws(s).w_cam_tab.ensure((size_t)(C.w + C.h) * 4)) return rc;
-  if (ws(s).w_cam_tab.cap != tab_cap) ws(s).cam_tab_ok = false;      // a new allocation (maybe at the old address)
+  const DevCamera& C = cams[0];
+  const size_t tab_cap = ws(s).w_cam_tab.cap, fr_cap = ws(s).w_frames.cap;
+  const size_t tab_words = (size_t)(C.w + C.h);
+  if (int rc = ws(s).w_cam_tab.ensure(tab_words * nframes * 4)) return rc;
+  if (nframes > 1) { if (int rc = ws(s).w_frames.ensure((size_t)nframes * 64)) return rc; }
+  if (ws(s).w_cam_tab.cap != tab_cap || ws(s).w_frames.cap != fr_cap) ws(s).cam_tab_ok = false;      // a new allocation (maybe at the old address)
   Primary pr; pr.camera = true; pr.C = C; pr.n0 = npix; pr.tiles = tiles; pr.bounce0 = 0;
   pr.C.tab = ws(s).w_cam_tab.as<float>();
-  // the tables depend on the camera and the rectangle only: frames of one camera reuse them
-  if (!ws(s).cam_tab_ok || std::memcmp(&ws(s).cam_tab_of, &pr.C, sizeof(DevCamera)) != 0) {
-    hipLaunchKernelGGL(k_camera_tables, dim3((uint32_t)(C.w + C.h + 255) / 256), dim3(256), 0, ws(s).stream, pr.C, ws(s).w_cam_tab.as<float>());
-    ws(s).cam_tab_of = pr.C; ws(s).cam_tab_ok = true;
+  pr.C.frames = nframes > 1 ? ws(s).w_frames.as<float>() : nullptr;
+  // the tables depend on the cameras and the rectangle only: frames of the same cameras reuse them
+  std::vector<DevCamera>& held = ws(s).cam_tab_of;
+  if (!ws(s).cam_tab_ok || held.size() != nframes || std::memcmp(held.data(), cams, sizeof(DevCamera) * nframes) != 0) {
+    for (uint32_t f = 0; f < nframes; ++f)
+      hipLaunchKernelGGL(k_camera_tables, dim3((uint32_t)(tab_words + 255) / 256), dim3(256), 0, ws(s).stream, cams[f],
+                         ws(s).w_cam_tab.as<float>() + tab_words * f);
+    if (nframes > 1) {
+      FrameBatch B;
+      std::memset(&B, 0, sizeof B);
+      for (uint32_t f = 0; f < nframes; ++f) {
+        std::memcpy(B.rec[f], cams[f].inv34, 12 * sizeof(float));
+        std::memcpy(B.rec[f] + 12, cams[f].origin, 3 * sizeof(float));
+      }
+      hipLaunchKernelGGL(k_store_frames, dim3(1), dim3(16 * kMaxBatch), 0, ws(s).stream, B, nframes, ws(s).w_frames.as<float>());
+    }
+    held.assign(cams, cams + nframes); ws(s).cam_tab_ok = true;
   }
+  pr.cams = cams; pr.nframes = nframes;
   if (int rc = run_pipeline(s, pr, opt, rgb, t, face)) return rc;
-  uint64_t live = npix;
+  uint64_t live = C.frame_slots ? C.frame_slots : npix;
   if (C.ts) {   // partial edge tiles: count only slots that are pixels of the rectangle
     live = 0;
     const int tiles_y = (C.h + C.ts - 1) / C.ts;
@@ -1365,7 +1424,7 @@ static int render_impl(rtx_scene* s, const DevCamera& C, uint32_t npix, uint32_t
       live += (uint64_t)std::min(C.ts, C.w - gx * C.ts) * (uint64_t)std::min(C.ts, C.h - gy * C.ts);
     }
   }
-  cur_call(s).stats.rays_primary = live;
+  cur_call(s).stats.rays_primary = live * nframes;
   cur_call(s).tune = true;
   if (wait) return stats_end(s);
   stats_enqueue_end(s);
@@ -1636,7 +1695,7 @@ static int render_multi(rtx_scene* const* scenes, int32_t n, const rtx_camera* c
   int first_err = RTX_OK;
   int queued = 0;
   for (int i = 0; i < n && first_err == RTX_OK; ++i) {
-    first_err = render_tiles_impl(scenes[i], cam, opt, rect, tile_size, i, n, (float*)part_ptr(i, 0), (float*)part_ptr(i, 1),
+    first_err = render_tiles_impl(scenes[i], cam, 1, opt, rect, tile_size, i, n, (float*)part_ptr(i, 0), (float*)part_ptr(i, 1),
                                   (int32_t*)part_ptr(i, 2), false);
     if (first_err == RTX_OK) ++queued;
   }

@@ -104,7 +104,13 @@ struct DevCamera {
   // compact pixels [k*ts*ts, (k+1)*ts*ts), row-major inside the tile.  ts == 0: plain
   // row-major rectangle.
   int ts, part, nparts, tiles_x;
-  uint32_t ntiles_local, pad_;
+  uint32_t ntiles_local;
+  // A batch of frames in one call (rtx_render_tiles_batch_dev): nframes cameras over the same rectangle / tile
+  // partition; frame f's output slots are [f * frame_slots, (f + 1) * frame_slots), its 16x16 pixel blocks
+  // [f * frame_blocks, ...), its tables at tab + f * (w + h), its inverse view and centre in frames[16 f ..]
+  // (12 + 3 floats + pad).  nframes == 1: the fields above, nothing read from `frames`.
+  uint32_t nframes, frame_slots, frame_blocks;
+  const float* frames;
   const float* tab;    // nx of the w columns, then ny of the h rows (k_camera_tables)
 };
 
@@ -249,21 +255,38 @@ __global__ void k_camera_tables(DevCamera C, float* tab) {
   if (i < C.w) tab[i] = camera_nx(C, (float)(C.x0 + i) + C.sub[0]);
   else if (i < C.w + C.h) tab[i] = camera_ny(C, (float)(C.y0 + (i - C.w)) + C.sub[1]);
 }
+// The per-frame records of a batch travel as kernel arguments (no host buffer to keep alive behind an async copy).
+constexpr int kMaxBatch = 16;
+struct FrameBatch { float rec[kMaxBatch][16]; };
+__global__ void k_store_frames(FrameBatch B, uint32_t n, float* dst) {
+  const uint32_t i = threadIdx.x;
+  if (i < 16u * n) dst[i] = B.rec[i >> 4][i & 15];
+}
 // Ray of pixel (lx, ly) of the rectangle (relative coordinates).
-__device__ __forceinline__ void camera_ray(const DevCamera& C, int lx, int ly, V3* o, V3* d1) {
-  const float nx = C.tab[lx], ny = C.tab[C.w + ly];
+__device__ __forceinline__ void camera_ray_of(const float* M, const float* c, float nx, float ny, V3* o, V3* d1) {
   const float nz = -1.0f;
   V3 w;
-  w.x = ((C.inv34[0] * nx + C.inv34[1] * ny) + C.inv34[2] * nz) + C.inv34[3] * 1.0f;
-  w.y = ((C.inv34[4] * nx + C.inv34[5] * ny) + C.inv34[6] * nz) + C.inv34[7] * 1.0f;
-  w.z = ((C.inv34[8] * nx + C.inv34[9] * ny) + C.inv34[10] * nz) + C.inv34[11] * 1.0f;
-  const V3 org = v3(C.origin[0], C.origin[1], C.origin[2]);
+  w.x = ((M[0] * nx + M[1] * ny) + M[2] * nz) + M[3] * 1.0f;
+  w.y = ((M[4] * nx + M[5] * ny) + M[6] * nz) + M[7] * 1.0f;
+  w.z = ((M[8] * nx + M[9] * ny) + M[10] * nz) + M[11] * 1.0f;
+  const V3 org = v3(c[0], c[1], c[2]);
   *o = org;
   *d1 = normalized(w - org);
 }
+__device__ __forceinline__ void camera_ray(const DevCamera& C, uint32_t f, int lx, int ly, V3* o, V3* d1) {
+  if (C.nframes > 1) {          // frame f of a batch: its own view and tables
+    const float* tab = C.tab + (size_t)f * (uint32_t)(C.w + C.h);
+    const float* fr = C.frames + 16u * f;
+    camera_ray_of(fr, fr + 12, tab[lx], tab[C.w + ly], o, d1);
+    return;
+  }
+  camera_ray_of(C.inv34, C.origin, C.tab[lx], C.tab[C.w + ly], o, d1);
+}
 // Output slot p -> pixel (x, y) relative to the rectangle; false for the dead slots of
 // partial edge tiles in the tiled-compact layout.
-__device__ __forceinline__ bool slot_pixel(const DevCamera& C, uint32_t p, int* px, int* py) {
+__device__ __forceinline__ bool slot_pixel(const DevCamera& C, uint32_t p, uint32_t* frame, int* px, int* py) {
+  *frame = 0;
+  if (C.nframes > 1) { *frame = p / C.frame_slots; p -= *frame * C.frame_slots; }
   if (C.ts == 0) { *px = (int)(p % (uint32_t)C.w); *py = (int)(p / (uint32_t)C.w); return true; }
   const uint32_t tt = (uint32_t)(C.ts * C.ts);
   const uint32_t k = p / tt, in = p % tt;
@@ -275,13 +298,17 @@ __device__ __forceinline__ bool slot_pixel(const DevCamera& C, uint32_t p, int* 
 }
 // (block, thread) -> output slot: a block covers 16x16 pixels, a wave an 8x8 sub-tile, so
 // that the 64 rays of a wave stay coherent.  Returns false where there is no pixel.
-__device__ __forceinline__ bool block_slot(const DevCamera& C, uint32_t block, uint32_t tid, uint32_t* slot, int* px, int* py) {
+__device__ __forceinline__ bool block_slot(const DevCamera& C, uint32_t block, uint32_t tid, uint32_t* frame, uint32_t* slot, int* px, int* py) {
   const uint32_t wave = tid >> 6, lane = tid & 63;
+  uint32_t f = 0;
+  if (C.nframes > 1) { f = block / C.frame_blocks; block -= f * C.frame_blocks; }
+  *frame = f;
+  const uint32_t slot0 = f * C.frame_slots;
   const int ix = (int)((wave & 1) * 8 + (lane & 7)), iy = (int)((wave >> 1) * 8 + (lane >> 3));
   if (C.ts == 0) {
     const uint32_t bxn = (uint32_t)(C.w + 15) >> 4;
     const int lx = (int)(block % bxn) * 16 + ix, ly = (int)(block / bxn) * 16 + iy;
-    *px = lx; *py = ly; *slot = (uint32_t)ly * (uint32_t)C.w + (uint32_t)lx;
+    *px = lx; *py = ly; *slot = slot0 + (uint32_t)ly * (uint32_t)C.w + (uint32_t)lx;
     return lx < C.w && ly < C.h;
   }
   const uint32_t sub_n = (uint32_t)(C.ts >> 4);                 // 16x16 blocks per tile side
@@ -289,7 +316,7 @@ __device__ __forceinline__ bool block_slot(const DevCamera& C, uint32_t block, u
   const int tx = (int)(sb % sub_n) * 16 + ix, ty = (int)(sb / sub_n) * 16 + iy;
   const uint32_t g = k * (uint32_t)C.nparts + (uint32_t)C.part;
   const int x = (int)(g % (uint32_t)C.tiles_x) * C.ts + tx, y = (int)(g / (uint32_t)C.tiles_x) * C.ts + ty;
-  *px = x; *py = y; *slot = k * (uint32_t)(C.ts * C.ts) + (uint32_t)(ty * C.ts + tx);
+  *px = x; *py = y; *slot = slot0 + k * (uint32_t)(C.ts * C.ts) + (uint32_t)(ty * C.ts + tx);
   return x < C.w && y < C.h;
 }
 
@@ -454,10 +481,10 @@ __device__ __forceinline__ float shadow_tmax(V3 light, V3 P) { return norm(light
 struct CameraSource {
   DevCamera C;
   __device__ __forceinline__ bool get(uint32_t j, V3* o, V3* d1, uint32_t* slot, float* tmax) const {
-    int lx, ly;
+    int lx, ly; uint32_t f;
     *tmax = INFINITY;
-    if (!block_slot(C, j / kBlock, j % kBlock, slot, &lx, &ly)) return false;
-    camera_ray(C, lx, ly, o, d1);
+    if (!block_slot(C, j / kBlock, j % kBlock, &f, slot, &lx, &ly)) return false;
+    camera_ray(C, f, lx, ly, o, d1);
     return true;
   }
   __device__ __forceinline__ bool first_hit_decides() const { return false; }
@@ -755,10 +782,10 @@ __device__ __forceinline__ void guard_and_verify(const DevScene& S, const Source
 struct PlainCameraSource {          // the pixels of the rectangle in slot order (no 16x16 block mapping)
   DevCamera C;
   __device__ __forceinline__ bool get(uint32_t j, V3* o, V3* d1, uint32_t* slot, float* tmax) const {
-    int x, y;
+    int x, y; uint32_t f;
     *tmax = INFINITY; *slot = j;
-    if (!slot_pixel(C, j, &x, &y)) return false;
-    camera_ray(C, x, y, o, d1);
+    if (!slot_pixel(C, j, &f, &x, &y)) return false;
+    camera_ray(C, f, x, y, o, d1);
     return true;
   }
 };
@@ -1020,9 +1047,9 @@ __device__ __forceinline__ float acc_value(long long v, uint32_t flags) {
 __device__ __forceinline__ RayRec load_node(const PipeArgs& A, uint32_t i) {
   RayRec r;
   if (A.from_camera) {
-    int x, y;
-    r.valid = slot_pixel(A.C, i, &x, &y);
-    camera_ray(A.C, x, y, &r.o, &r.d1);
+    int x, y; uint32_t f;
+    r.valid = slot_pixel(A.C, i, &f, &x, &y);
+    camera_ray(A.C, f, x, y, &r.o, &r.d1);
     r.pixel = i; r.thr = 1.0f; r.inside = false;
     return r;
   }
@@ -1124,7 +1151,7 @@ __device__ __forceinline__ uint32_t wave_alloc_lds(bool want, uint32_t* lds_coun
 struct Spawn { bool valid, hit, refl, refr; float ht; int id; };
 __device__ __forceinline__ Spawn classify(const PipeArgs& A, uint32_t i) {
   Spawn sp; sp.valid = true; sp.hit = sp.refl = sp.refr = false; sp.ht = INFINITY; sp.id = -1;
-  if (A.from_camera) { int x, y; sp.valid = slot_pixel(A.C, i, &x, &y); }
+  if (A.from_camera) { int x, y; uint32_t f; sp.valid = slot_pixel(A.C, i, &f, &x, &y); }
   if (!sp.valid) return sp;
   const uint2 h = A.hits[i];
   sp.ht = __uint_as_float(h.x); sp.id = (int)h.y;
@@ -1361,7 +1388,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(PipeArgs A) {
 // The fixed-point sums of a ray-tree call -> the caller's float pixels (slots of partial edge tiles stay untouched).
 __global__ __launch_bounds__(kBlock) void k_acc_to_rgb(PipeArgs A) {
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < A.n0; i += gridDim.x * kBlock) {
-    if (A.from_camera) { int x, y; if (!slot_pixel(A.C, i, &x, &y)) continue; }
+    if (A.from_camera) { int x, y; uint32_t f; if (!slot_pixel(A.C, i, &f, &x, &y)) continue; }
     const uint32_t f = A.acc_flag[i];
     for (int c = 0; c < 3; ++c) A.rgb[3 * (size_t)i + c] = acc_value(A.acc[3 * (size_t)i + c], (f >> (3 * c)) & 7u);
   }

@@ -1,0 +1,88 @@
+"""rtx_render_tiles_batch_dev: several cameras over one rectangle / tile partition in one set of launches.  Every
+frame of a batch must be, bit for bit, what rtx_render_tiles_dev (tile_size 0: rtx_render_dev) gives for that camera
+alone -- hit ids, t and RGB (the per-frame values do not depend on what else a launch carries)."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal, load_scene_fixture, rtx_materials
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    from raytracing_project_amd import api
+    assert api.lib().rtx_device_count() >= 1, "no GPU visible: the HIP path cannot run (there is no fallback)"
+    return api
+
+
+def _cams(api, fx, W, H):
+    return [api.make_camera(fx["view_default"], W, H), api.make_camera(fx["view_oblique"], W, H, subpixel=(0.25, 0.75)),
+            api.make_camera(fx["view_top"], W, H), api.make_camera(fx["view_oblique"], W, H),
+            api.make_camera(fx["view_default"], W, H, subpixel=(0.5, 0.125))]
+
+
+@pytest.mark.parametrize("scene_name,opts_t", [("spheres", (2, 1, 0, 0, 1, 0)), ("toy", (3, 1, 1, 0, 1, 0)), ("bunny", (0, 0, 0, 0, 1, 0))])
+def test_batch_frames_equal_single_frames(api, scene_name, opts_t):
+    import torch
+    fx = load_scene_fixture(scene_name)
+    s = api.Scene(fx["verts"], fx["idx"], fx["tri_mat"], rtx_materials(fx["mats"]))
+    s.set_lights([[-1.0, 1.0, 1.0], [1.0, 2.0, 0.5]])
+    s.commit(0)
+    opts = api.Options(*opts_t)
+    W, H = 150, 83                      # partial edge tiles on both sides
+    rect = (0, 0, W, H)
+    cams = _cams(api, fx, W, H)
+    dev = torch.device("cuda", 0)
+
+    def bufs(n):
+        return (torch.full((n, 3), -7.0, dtype=torch.float32, device=dev), torch.full((n,), -7.0, dtype=torch.float32, device=dev),
+                torch.full((n,), -9, dtype=torch.int32, device=dev))
+
+    for ts, part, nparts in ((32, 1, 3), (16, 0, 1), (32, 2, 8), (0, 0, 1)):
+        P = W * H if ts == 0 else api.lib().rtx_tiles_count(api.Rect(*rect), ts, part, nparts) * ts * ts
+        singles = []
+        for cam in cams:
+            rgb, t, face = bufs(P)
+            torch.cuda.synchronize()
+            if ts == 0:
+                s.render_dev(cam, opts, rect, rgb.data_ptr(), t.data_ptr(), face.data_ptr())
+            else:
+                s.render_tiles_dev(cam, opts, rect, ts, part, nparts, rgb.data_ptr(), t.data_ptr(), face.data_ptr())
+            singles.append((rgb.cpu().numpy(), t.cpu().numpy(), face.cpu().numpy(), s.stats()))
+        for F in (1, 2, 5):
+            rgb, t, face = bufs(F * P)
+            torch.cuda.synchronize()
+            s.render_tiles_batch_dev(cams[:F], opts, rect, ts, part, nparts, rgb.data_ptr(), t.data_ptr(), face.data_ptr())
+            st = s.stats()
+            rgb, t, face = rgb.cpu().numpy().reshape(F, P, 3), t.cpu().numpy().reshape(F, P), face.cpu().numpy().reshape(F, P)
+            for f in range(F):
+                what = "%s frame %d of %d, tile %d part %d/%d" % (scene_name, f, F, ts, part, nparts)
+                assert np.array_equal(face[f], singles[f][2]), what
+                assert_bits_equal(t[f], singles[f][1], "t " + what)
+                assert_bits_equal(rgb[f], singles[f][0], "rgb " + what)
+            # the batch's statistics count the rays of all its frames
+            assert st.rays_primary == sum(x[3].rays_primary for x in singles[:F])
+            assert st.rays_shadow == sum(x[3].rays_shadow for x in singles[:F])
+            assert st.rays_reflection == sum(x[3].rays_reflection for x in singles[:F])
+    # enqueue form: two batches in flight with different cameras, finished in order
+    P = api.lib().rtx_tiles_count(api.Rect(*rect), 32, 0, 2) * 32 * 32
+    a, b = bufs(3 * P), bufs(2 * P)
+    torch.cuda.synchronize()
+    s.render_tiles_batch_dev(cams[:3], opts, rect, 32, 0, 2, a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), enqueue=True)
+    s.render_tiles_batch_dev(cams[3:], opts, rect, 32, 0, 2, b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr(), enqueue=True)
+    sa, sb = s.render_finish(), s.render_finish()
+    for k, cam in enumerate(cams):
+        rgb, t, face = bufs(P)
+        torch.cuda.synchronize()
+        s.render_tiles_dev(cam, opts, rect, 32, 0, 2, rgb.data_ptr(), t.data_ptr(), face.data_ptr())
+        got = (a, k) if k < 3 else (b, k - 3)
+        assert torch.equal(got[0][2].view(-1, P)[got[1]], face)
+        assert torch.equal(got[0][0].view(-1, P, 3)[got[1]].view(torch.int32), rgb.view(torch.int32))
+    assert sa.rays_primary * 2 == sb.rays_primary * 3
+    # limits and argument checks
+    with pytest.raises(api.RtxError, match="1 to 16 frames"):
+        s.render_tiles_batch_dev(cams * 4, opts, rect, 32, 0, 2, a[0].data_ptr(), None, None)
+    with pytest.raises(api.RtxError, match="part 0 of 1"):
+        s.render_tiles_batch_dev(cams[:2], opts, rect, 0, 1, 2, a[0].data_ptr(), None, None)
+    s.close()
