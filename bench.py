@@ -287,9 +287,12 @@ def main():
             return [frame() for _ in range(n)]
         flying = []
         left = n
+        ncalls = (n + B - 1) // B                # calls of (nearly) equal size: 20 frames at B = 8 go as 7 + 7 + 6
         while left > 0:
-            flying.append(batch_enqueue(min(B, left)))
-            left -= min(B, left)
+            nf = (left + ncalls - 1) // ncalls
+            ncalls -= 1
+            flying.append(batch_enqueue(nf))
+            left -= nf
             if len(flying) >= args.inflight:
                 out.append(batch_finish(flying.pop(0)))
         while flying:
@@ -327,15 +330,17 @@ def main():
     # Per-kernel durations for the roofline: frames in flight share the GPU, so the HIP-event spans of the timed
     # region include time given to the other frames' kernels.  The same frames once more, one at a time
     # (synchronous calls, nothing beside them): these spans are each kernel's own duration.
+    # (the same launches as in the timed region: B frames per call)
     ms_iso = None
     if world == 1:
         ms_iso = np.zeros(3, np.float64)
-        for _ in range(args.steps):
+        ncalls = max(2, args.steps // B)
+        for _ in range(ncalls):
             for cam in cams:
-                scene.render_dev(cam, opts, rect, sets[0]["rgb"].data_ptr(), None, sets[0]["face"].data_ptr())
+                scene.render_tiles_batch_dev([cam] * B, opts, rect, 0, 0, 1, sets[0]["rgb"].data_ptr(), None, sets[0]["face"].data_ptr())
                 st = scene.stats()
                 ms_iso += [st.ms_trace_camera, st.ms_trace - st.ms_trace_camera, st.ms_total]
-        ms_iso /= args.steps
+        ms_iso /= ncalls * B
     # pixels whose primary ray hit geometry, from the hit ids of the last frame on every rank
     last = sets[(state["k"] - 1) % NSETS]["face"][:npix_local]
     nhit = torch.tensor([float((last >= 0).sum().item())], dtype=torch.float64, device="cpu" if rehearse else dev)
@@ -375,8 +380,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_scaling_proxy:
         result["scaling_proxy"] = scaling_proxy(scene, cams[0], opts, rect, W, H, torch, dev, tiles, max(5, args.steps), args.inflight, B)
     if rank == 0 and world == 1 and not args.no_roofline:
-        result["config"]["kernel_ms_per_frame_one_at_a_time"] = {"trace_camera": ms_iso[0], "trace_queue": ms_iso[1], "all_kernels": ms_iso[2]}
-        result["roofline"] = roofline(args, wl, scene, info, ms_iso, rays_tot / args.steps)
+        result["config"]["kernel_ms_per_frame_one_call_at_a_time"] = {"trace_camera": ms_iso[0], "trace_queue": ms_iso[1], "all_kernels": ms_iso[2]}
+        result["roofline"] = roofline(args, wl, scene, info, ms_iso, rays_tot / args.steps, B)
         ent = result["roofline"]["rays_entering_bvh_per_frame"]
         # rays that pass the reference's root-box gate and walk the hierarchy (the rest end at the gate: the camera of
         # SURVEY 8(d) sees past the soup on more than half of the frame)
@@ -451,10 +456,12 @@ def any_blocker_shadows(wl):
     return all(key(x) == key(m[0]) for x in m) and bool((tm >= 0).all() and (tm < len(m)).all())
 
 
-def roofline(args, wl, scene, info, ms, rays):
+def roofline(args, wl, scene, info, ms, rays, frames_per_launch=1):
     """The dominant traversal kernel against the rooflines that could bound it.
 
-    ms: per-frame kernel durations measured one frame at a time (HIP events on the library's stream).
+    ms: per-frame kernel durations measured one render call at a time (HIP events on the library's stream); a call's
+    launches carry frames_per_launch frames (rtx_render_tiles_batch_dev), and every per-launch figure below is for
+    such a launch.
     * algorithmic_bytes_per_launch: SURVEY 8(d)'s figure, 32 B per node visited + 36 B per triangle tested + io,
       counted by the CPU mirror (oracle/rt_oracle_bvh.c) walking the same BVH in the same order on every k-th
       pixel's rays (shadow rays bounded at the light and stopped at any blocker exactly where the kernel does).
@@ -510,12 +517,13 @@ def roofline(args, wl, scene, info, ms, rays):
         per_ray.update({"shadow_nodes": float(nv2.mean()), "shadow_tris": float(tt2.mean()),
                         "shadow_rays_stop_at_any_blocker": bool(anyhit)})
     spp = wl["spp"]
-    cand = [("k_trace_camera", prim_bytes, prim_layout, ms[0] / spp), ("k_trace_queue", sh_bytes, sh_layout, ms[1] / spp)]
+    B = frames_per_launch
+    cand = [("k_trace_camera", prim_bytes * B, prim_layout * B, ms[0] / spp * B), ("k_trace_queue", sh_bytes * B, sh_layout * B, ms[1] / spp * B)]
     if wl["opts"][0] > 0:     # reflection launches share k_trace_queue's time; only the camera kernel is attributable
         cand = cand[:1]
     name, nbytes, lbytes, kms = max(cand, key=lambda c: c[3])
     scene_bytes = 64.0 * (info.nnodes / 4.0) + 64.0 * info.ntris + 4.0 * info.ntris
-    io_bytes = 8.0 * W * H if name == "k_trace_camera" else 40.0 * rays[1] / spp
+    io_bytes = (8.0 * W * H if name == "k_trace_camera" else 40.0 * rays[1] / spp) * B
     compulsory = scene_bytes + io_bytes
     pmc = {}
     try:
@@ -528,7 +536,7 @@ def roofline(args, wl, scene, info, ms, rays):
     hbm_bytes = traffic if traffic is not None else compulsory
     res = {"bound": "hbm", "kernel": name, "unit": "GB/s", "peak": HBM_PEAK_GBS,
            "achieved": hbm_bytes / sec / 1e9 if sec > 0 else 0.0,
-           "traffic": traffic, "avg_launch_ms": kms,
+           "traffic": traffic, "avg_launch_ms": kms, "frames_per_launch": B,
            "achieved_is": ("HBM-side bytes per launch (traffic: PMC FETCH_SIZE x2 + WRITE_SIZE, %s) / the launch duration measured in this run"
                            % PMC_FILE) if traffic is not None else "compulsory bytes per launch (no PMC record for this workload) / measured launch duration",
            "compulsory_bytes_per_launch": compulsory,
@@ -550,7 +558,7 @@ def roofline(args, wl, scene, info, ms, rays):
                        "frac": pmc["valu_busy"] * pmc["active_lanes"],
                        "waves_per_simd": pmc.get("waves_per_simd"), "ta_busy": pmc.get("ta_busy"), "td_busy": pmc.get("td_busy"),
                        "note": "the bound that binds: share of the kernel's SIMD cycles issuing vector ALU instructions x active lanes "
-                               "per instruction (%s, rocprofv3 --pmc SQ passes of this command with --inflight 1)" % PMC_FILE}
+                               "per instruction (%s, rocprofv3 --pmc SQ passes of this command with --inflight 1: one call at a time)" % PMC_FILE}
         res["binding_bound"] = "valu"
     res["rays_entering_bvh_per_frame"] = {k: v * spp for k, v in entering.items()}
     # the same traversal of the same BVH on the host's cores (the "same algorithm on the CPU" figure of SURVEY 8(d))

@@ -138,6 +138,8 @@ struct rtx_scene {
     bool pending = false;              // enqueued, not finished yet
     bool tunable = false;              // a render call: its launches may be tuner trials (set before the first launch)
     bool throughput = false;           // enqueued, and other calls may run beside it
+    bool alone = false;                // its launches may be tuner trials: no other call runs beside it
+    int bucket = 0;                    // size class of the call (primary rays), selects the tuner state
     bool unreported = false;           // enqueued by rtx_render_*_enqueue and not yet handed out by rtx_render_finish
     bool pipeline = false, shade = false, shadows = false, tune = false;   // what finish_call has to account for
     int max_gen = 0;
@@ -146,17 +148,19 @@ struct rtx_scene {
   };
   Call calls[kSlots];
   int cur = 0;
-  // Scheduler tuning per launch kind (camera / shadow queue / bounce queue): after a first untimed
-  // call, the next calls of a scene run the scheduler modes in turn on the real work, twice each, and
+  // Scheduler tuning per launch kind (camera / shadow queue / bounce queue) and size class of the call (its
+  // primary rays, classes a factor of 4 wide: a frame, a batch of 8 frames and a 1/8 share each have a state of
+  // their own, and calls of different sizes taking turns do not disturb each other): after a first untimed
+  // call, the next calls of a class run the scheduler modes in turn on the real work, twice each, and
   // the fastest is kept (results are identical whichever runs, tests/test_gpu_parity.py).
   struct Tune {
     bool started = false, too_small = false;
     int choice = -1;
     int launched[3] = {0, 0, 0}, done[3] = {0, 0, 0};
     double ms_per_ray[3] = {0, 0, 0};
-    uint64_t rays_ref = 0;
   };
-  Tune tune[3];
+  static constexpr int kBuckets = 16;
+  Tune tune[3][kBuckets];
   rtx_stats stats{};                   // of the last finished call
   rtx_scene_info info{};
   int ncu = 256;
@@ -632,6 +636,7 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   in.device_bytes = s->d_nodes.cap + s->d_tris.cap + s->d_tri_face.cap + s->d_face_nm.cap + s->d_spheres.cap +
                     s->d_sph_mat.cap + s->d_mats.cap + s->d_lights.cap + s->d_slights.cap + s->d_leafboxes.cap +
                     s->d_leaf_faces.cap + s->d_face_pos.cap;
+  for (auto& per_kind : s->tune) for (rtx_scene::Tune& T : per_kind) T = rtx_scene::Tune();     // another scene on this handle: the tuner starts over
   s->committed = true;
   return RTX_OK;
 }
@@ -719,15 +724,24 @@ static int finish_call(rtx_scene* s, rtx_scene::Call& c) {
 }
 // Every call starts here: takes the call slot that is not the most recent one (finishing what it
 // still holds) and opens the span of the whole call.
-static bool overlap_frames(const rtx_scene* s);
-static int stats_begin(rtx_scene* s) {
+static bool bucket_settled(const rtx_scene* s, int bucket);
+static int size_bucket(uint64_t n0) {
+  int lg = 0;
+  while (lg < 62 && (2ull << lg) <= n0) ++lg;          // floor(log2(n0)), 0 for n0 <= 1
+  return std::min(lg / 2, rtx_scene::kBuckets - 1);
+}
+static int stats_begin(rtx_scene* s, uint64_t n0 = 0) {
   s->cur = (s->cur + 1) % kSlots;          // the slot used longest ago
   rtx_scene::Call& c = cur_call(s);
   if (int rc = finish_call(s, c)) return rc;
   c.unreported = false;
-  // The other slot's call may still be running on its own streams: this call then runs beside it.  While the
-  // scheduler tuner is timing launches, calls run one at a time.
-  if (!overlap_frames(s))
+  // The other slots' calls may still be running on their own streams: this call then runs beside them -- unless the
+  // scheduler tuner may time this call's launches or those of a call in flight: such calls have the GPU to themselves.
+  c.bucket = size_bucket(n0);
+  c.alone = !bucket_settled(s, c.bucket);
+  bool others_alone = false;
+  for (int i = 1; i < kSlots; ++i) { const rtx_scene::Call& o = s->calls[(s->cur + i) % kSlots]; others_alone = others_alone || (o.pending && o.alone); }
+  if (c.alone || others_alone)
     for (int i = 1; i < kSlots; ++i) if (int rc = finish_call(s, s->calls[(s->cur + i) % kSlots])) return rc;
   c.events.reset(); c.trace_spans.clear(); c.all_spans.clear(); c.camera_span = (size_t)-1;
   c.span_kind.clear();
@@ -799,7 +813,7 @@ static int sched_pick(rtx_scene* s, int kind, uint64_t rays) {
   if (s->flags & RTX_FLAG_SCHED_GROUPS) return SCHED_GROUPS;
   if (sched_forced() >= 0) return sched_forced();
   if (c.mode[kind] >= 0) return c.mode[kind];          // one mode per kind and call
-  rtx_scene::Tune& T = s->tune[kind];
+  rtx_scene::Tune& T = s->tune[kind][c.bucket];
   int m;
   if (T.choice >= 0) m = T.choice;
   else if (!c.tunable) m = sched_heuristic(s, kind, rays);   // a query call: never accounted by tune_update, so it takes no trial
@@ -827,11 +841,9 @@ static void tune_update(rtx_scene* s, rtx_scene::Call& c) {
   }
   const uint64_t rays[3] = {c.stats.rays_primary, c.stats.rays_shadow, c.stats.rays_reflection + c.stats.rays_refraction};
   for (int k = 0; k < 3; ++k) {
-    rtx_scene::Tune& T = s->tune[k];
+    rtx_scene::Tune& T = s->tune[k][c.bucket];
     if (!seen[k] || rays[k] == 0) continue;
-    if (T.rays_ref && (rays[k] > 2 * T.rays_ref || 2 * rays[k] < T.rays_ref)) { T = rtx_scene::Tune(); T.started = true; }   // another workload: start over
     if (T.choice >= 0) continue;
-    if (T.rays_ref == 0) T.rays_ref = rays[k];
     const int m = c.mode[k];
     if (rays[k] < kTuneMinRays) {                       // not worth timing: the heuristic from now on
       T.too_small = true;
@@ -861,22 +873,24 @@ static void tune_update(rtx_scene* s, rtx_scene::Call& c) {
 }
 // Overlapped bounce launches (run_pipeline): RTX_OVERLAP=0 never, =1 always; by default once the tuner has
 // settled the shadow and the bounce queue of this scene (its trial frames time one launch at a time).
-static bool overlap_launches(const rtx_scene* s) {
+static bool overlap_launches(rtx_scene* s) {
   static const int forced = [] { const char* e = std::getenv("RTX_OVERLAP"); return e ? std::atoi(e) : -1; }();
   if (forced == 0) return false;
   if (forced > 0) return true;
   if ((s->flags & (RTX_FLAG_SCHED_REFILL | RTX_FLAG_SCHED_GROUPS)) || sched_forced() >= 0) return true;
-  return s->tune[KIND_SHADOW].choice >= 0 && s->tune[KIND_BOUNCE].choice >= 0;
+  const int b = cur_call(s).bucket;
+  return s->tune[KIND_SHADOW][b].choice >= 0 && s->tune[KIND_BOUNCE][b].choice >= 0;
 }
-// Two calls in flight run side by side on the two slots' streams (RTX_OVERLAP_FRAMES=0 never, =1 always): by
-// default once every launch kind this scene has used is settled in the tuner, whose trials need the GPU alone.
-static bool overlap_frames(const rtx_scene* s) {
+// Calls in flight run side by side on their slots' streams (RTX_OVERLAP_FRAMES=0 never, =1 always): by default
+// once every launch kind that calls of this size class have used is settled in the tuner, whose trials need the GPU alone.
+static bool bucket_settled(const rtx_scene* s, int bucket) {
   static const int forced = [] { const char* e = std::getenv("RTX_OVERLAP_FRAMES"); return e ? std::atoi(e) : -1; }();
   if (forced == 0) return false;
   if (forced > 0) return true;
   if ((s->flags & (RTX_FLAG_SCHED_REFILL | RTX_FLAG_SCHED_GROUPS)) || sched_forced() >= 0) return true;
   bool any = false;
-  for (const rtx_scene::Tune& T : s->tune) {
+  for (int k = 0; k < 3; ++k) {
+    const rtx_scene::Tune& T = s->tune[k][bucket];
     if (!T.started) continue;
     any = true;
     if (T.choice < 0 && !T.too_small) return false;
@@ -1382,8 +1396,8 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
 
 static int render_impl(rtx_scene* s, const DevCamera* cams, uint32_t nframes, uint32_t npix, uint32_t tiles, const rtx_options* opt,
                        float* rgb, float* t, int32_t* face, bool wait) {
-  if (int rc = stats_begin(s)) return rc;
-  cur_call(s).throughput = !wait && overlap_frames(s);
+  if (int rc = stats_begin(s, npix)) return rc;
+  cur_call(s).throughput = !wait && !cur_call(s).alone;
   cur_call(s).tunable = true;
   const DevCamera& C = cams[0];
   const size_t tab_cap = ws(s).w_cam_tab.cap, fr_cap = ws(s).w_frames.cap;
