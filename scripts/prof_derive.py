@@ -15,6 +15,9 @@ import sys
 NSIMD, NCU, NSE, NXCD = 1024, 256, 32, 8
 
 
+DISP = {}          # (kernel, counter) -> dispatches
+
+
 def load(files):
     d = {}
     for fn in files:
@@ -24,6 +27,7 @@ def load(files):
                 kern = re.sub(r"^void ", "", m.group(1).strip())
                 kern = re.sub(r"^rtx::", "", kern).split("(")[0]
                 d[(kern, m.group(2))] = float(m.group(5))
+                DISP[(kern, m.group(2))] = int(m.group(3))
     return d
 
 
@@ -43,7 +47,8 @@ def main():
     kernels = sorted({k for k, _ in d if k.startswith("k_")})
     if pmc_json:
         # what bench.py's roofline reads (profiles/rNN_pmc.json): per kernel, HBM-side bytes per launch and the
-        # vector-ALU figures; of a kernel's template variants the one that issued more VALU instructions counts
+        # vector-ALU figures; of a kernel's template variants the one launched most often counts (the scheduler the
+        # tuner settled on; the other variant's launches are its trials)
         out = {}
         for k in kernels:
             g = lambda c: d.get((k, c))  # noqa: E731
@@ -68,7 +73,8 @@ def main():
                 rec["l2_hit"] = g("TCC_HIT_sum") / g("TCC_REQ_sum")
             if not rec:
                 continue
-            if name in out and out[name].get("valu_insts", 0) >= rec.get("valu_insts", 0):
+            rec["launches_profiled"] = max([v for (kk, _), v in DISP.items() if kk == k] or [0])
+            if name in out and out[name]["launches_profiled"] >= rec["launches_profiled"]:
                 continue
             out[name] = rec
         print(json.dumps({pmc_json: out}, indent=1))
