@@ -48,7 +48,21 @@ def _worker(rank, world, port, W, H, ts, ret):
     parts2 = None
     for _ in range(2):
         parts2 = tiles.gather_to_root(local, world, rank, dist, pre)
+    # batches (bench.py with --batch): nf frames' tiles of a rank one after the other, gathered in ONE exchange into a
+    # slice of a buffer sized for the largest batch; frame f of every part is then reassembled on its own
+    nf, cap = 2, 3
+    npix = local.shape[0]
+    batch = torch.cat([local + 100000.0 * f for f in range(nf)])
+    big = torch.full((world, cap * npix, 3), -7.0) if rank == 0 else None
+    got = tiles.gather_to_root(batch, world, rank, dist, big[:, : nf * npix] if rank == 0 else None)
+    batch_ok = True
     if rank == 0:
+        for f in range(nf):
+            imgf = tiles.assemble(got[:, f * npix:(f + 1) * npix], W, H, ts, 3).numpy()
+            batch_ok = batch_ok and bool(np.array_equal(imgf, expected(W, H) + np.float32(100000.0 * f)))
+        batch_ok = batch_ok and bool((big[:, nf * npix:] == -7.0).all())
+    if rank == 0:
+        ret["batch_ok"] = batch_ok
         img = tiles.assemble(parts, W, H, ts, 3).numpy()
         img2 = tiles.assemble(parts2, W, H, ts, 3).numpy()
         ret["ok"] = bool(np.array_equal(img, expected(W, H))) and bool(np.array_equal(img2, expected(W, H))) and parts2 is pre
@@ -70,6 +84,7 @@ def test_gather_reassembles_frame(world, W, H, ts):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), W, H, ts, ret), nprocs=world, join=True)
     assert ret.get("ok") is True
+    assert ret.get("batch_ok") is True
 
 
 def test_single_rank_assemble_and_counts():
