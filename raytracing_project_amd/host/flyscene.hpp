@@ -27,12 +27,25 @@
 
 #include "../../include/rtx.h"
 
+// Call sites of the reference pass Eigen::Vector3f (src/flyscene.hpp:12-13): where Eigen is on the include path the facade's
+// vector converts from and to it implicitly, so those call sites compile unchanged; without Eigen nothing of it is needed.
+#if defined(__has_include)
+#if __has_include(<Eigen/Dense>) && !defined(RTXHOST_NO_EIGEN)
+#include <Eigen/Dense>
+#define RTXHOST_HAVE_EIGEN 1
+#endif
+#endif
+
 namespace rtxhost {
 
 struct Vector3f {
   float v[3];
   Vector3f() : v{0, 0, 0} {}
   Vector3f(float x, float y, float z) : v{x, y, z} {}
+#ifdef RTXHOST_HAVE_EIGEN
+  Vector3f(const Eigen::Vector3f& e) : v{e[0], e[1], e[2]} {}
+  operator Eigen::Vector3f() const { return Eigen::Vector3f(v[0], v[1], v[2]); }
+#endif
   float x() const { return v[0]; }
   float y() const { return v[1]; }
   float z() const { return v[2]; }
@@ -444,7 +457,7 @@ class Flyscene {
   Box root_box;                                                  // src/flyscene.hpp:219
 
   Flyscene() {}
-  ~Flyscene() { drop_replicas(); if (scene) rtx_scene_destroy(scene); }
+  ~Flyscene() { drop_replicas(); if (tri_scene) rtx_scene_destroy(tri_scene); if (scene) rtx_scene_destroy(scene); }
   Flyscene(const Flyscene&) = delete;
   Flyscene& operator=(const Flyscene&) = delete;
 
@@ -545,19 +558,23 @@ class Flyscene {
     return std::make_pair(h, f);
   }
   // src/flyscene.cpp:819-879: closest triangle of a face list; faceId indexes that list.
+  // The scene built for a face list is kept until another list (or other vertices) comes: the reference's callers ask
+  // ray after ray against the same leaf (src/flyscene.cpp:553-577).
   HitInfo intersectTriangle(std::vector<Tucano::Face>& faces, Vector3f origin, Vector3f dir) {
     std::vector<uint32_t> idx; idx.reserve(faces.size() * 3);
     for (auto& f : faces) for (int k = 0; k < 3; ++k) idx.push_back(f.vertex_ids[k]);
-    rtx_scene* tmp = nullptr;
-    rtx_check(rtx_scene_create(mesh.verts.data(), (uint32_t)(mesh.verts.size() / 3), idx.data(), nullptr, (uint32_t)faces.size(),
-                               nullptr, 0, &tmp));
+    if (!tri_scene || idx != tri_idx || mesh.verts != tri_verts) {
+      if (tri_scene) { rtx_scene_destroy(tri_scene); tri_scene = nullptr; }
+      rtx_scene* tmp = nullptr;
+      rtx_check(rtx_scene_create(mesh.verts.data(), (uint32_t)(mesh.verts.size() / 3), idx.data(), nullptr, (uint32_t)faces.size(),
+                                 nullptr, 0, &tmp));
+      int rc = rtx_scene_set_flags(tmp, RTX_FLAG_NO_ROOT_GATE);
+      if (rc >= 0) rc = rtx_scene_commit(tmp, device);
+      if (rc < 0) { std::string err = rtx_last_error(); rtx_scene_destroy(tmp); throw RtxError(rc, "rtx: " + err); }
+      tri_scene = tmp; tri_idx = idx; tri_verts = mesh.verts;
+    }
     HitInfo h{INFINITY, -1, Vector3f(), Vector3f()};
-    int rc = rtx_scene_set_flags(tmp, RTX_FLAG_NO_ROOT_GATE);
-    if (rc >= 0) rc = rtx_scene_commit(tmp, device);
-    if (rc >= 0) rc = rtx_trace_closest(tmp, origin.v, dir.v, 1, &h.t, &h.faceId, h.normal.v, h.point.v, nullptr);
-    std::string err = rc < 0 ? rtx_last_error() : "";
-    rtx_scene_destroy(tmp);
-    if (rc < 0) throw RtxError(rc, "rtx: " + err);
+    rtx_check(rtx_trace_closest(tri_scene, origin.v, dir.v, 1, &h.t, &h.faceId, h.normal.v, h.point.v, nullptr));
     return h;
   }
   // src/flyscene.cpp:906-972
@@ -671,6 +688,9 @@ class Flyscene {
   MeshData mesh;
   size_t mesh_materials = 0;
   rtx_scene* scene = nullptr;
+  rtx_scene* tri_scene = nullptr;            // intersectTriangle's face list, committed (kept between calls)
+  std::vector<uint32_t> tri_idx;
+  std::vector<float> tri_verts;
   bool dirty = true, spheres_added = false, frame_dirty = true;
   std::vector<float> frame;
   int frame_w = 0, frame_h = 0;

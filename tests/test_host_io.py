@@ -199,3 +199,22 @@ def test_obj_polygon_records_follow_tucano_and_bad_ply_counts_are_refused(tool, 
             f.write(hdr.encode()); f.write(body); f.write(struct.pack("<i", count)); f.write(struct.pack("<3i", 0, 1, 2))
         rc, err = run(tool, "ply", tmp_path / "bad.ply", tmp_path / "bad.bin")
         assert rc == 1 and "truncated PLY body" in err
+
+
+def test_facade_vectors_convert_from_and_to_eigen(tmp_path):
+    """With Eigen on the include path (the reference's vendored copy, where /root/reference is present) the facade's
+    Vector3f takes and gives Eigen::Vector3f implicitly: the reference's call sites (Ray(origin, dir), Box fields,
+    getDirection() into an Eigen variable) compile unchanged and the values agree bit for bit with Eigen's own."""
+    inc = "/root/reference/dependencies/eigen/include"
+    if not os.path.isdir(os.path.join(inc, "Eigen")):
+        pytest.skip("no Eigen headers here (the reference's vendored copy is absent)")
+    lib = os.path.join(ROOT, "raytracing_project_amd", "librtx.so")
+    if not os.path.exists(lib):
+        import __graft_entry__ as g
+        g.build()
+    exe = str(tmp_path / "eigen_interop")
+    subprocess.run(["g++", "-std=c++14", "-O2", "-ffp-contract=off", "-Wall", "-I" + inc, os.path.join(ROOT, "tests", "cpp", "eigen_interop.cpp"),
+                    "-o", exe, "-L" + os.path.join(ROOT, "raytracing_project_amd"), "-lrtx",
+                    "-Wl,-rpath," + os.path.join(ROOT, "raytracing_project_amd")], check=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "eigen interop ok" in r.stdout, r.stdout + r.stderr
