@@ -232,16 +232,44 @@ void build_bvh(const float* tri_lo, const float* tri_hi, uint32_t ntris, int thr
 namespace {
 // Fills group g with the (up to 4) grandchildren of binary node b; returns how many slots are in use and, per slot,
 // the binary node it came from.
-int fill_group(const std::vector<BvhNode>& bin, uint32_t b, std::vector<BvhNode>& q, uint32_t g, uint32_t depth, BvhBuildResult* out,
-               uint32_t cand[4]) {
-  // candidates: the two children of b, each replaced by its own children when internal
+// The (up to) four binary nodes that become the slots of b's group.
+//  greedy: start from b's two children and keep replacing the internal candidate with the largest surface by its
+//    own two children until four slots are taken -- a leaf child leaves its slot's worth of depth to the other side,
+//    and the big boxes (the ones most rays enter) are the ones opened;
+//  fixed: the children's children (two binary levels per group step, whatever they hold).
+bool g_greedy_collapse = true;
+int group_candidates(const std::vector<BvhNode>& bin, uint32_t b, uint32_t cand[4]) {
   int nc = 0;
   const uint32_t kids[2] = {bin[b].leftFirst, bin[b].leftFirst + 1};
-  for (int k = 0; k < 2; ++k) {
-    const BvhNode& c = bin[kids[k]];
-    if (c.count == 0) { cand[nc++] = c.leftFirst; cand[nc++] = c.leftFirst + 1; }
-    else cand[nc++] = kids[k];
+  if (!g_greedy_collapse) {
+    for (int k = 0; k < 2; ++k) {
+      const BvhNode& c = bin[kids[k]];
+      if (c.count == 0) { cand[nc++] = c.leftFirst; cand[nc++] = c.leftFirst + 1; }
+      else cand[nc++] = kids[k];
+    }
+    return nc;
   }
+  cand[nc++] = kids[0]; cand[nc++] = kids[1];
+  while (nc < 4) {
+    int pick = -1; float best = -1.0f;
+    for (int k = 0; k < nc; ++k) {
+      const BvhNode& c = bin[cand[k]];
+      if (c.count != 0) continue;
+      const float ex = c.hi[0] - c.lo[0], ey = c.hi[1] - c.lo[1], ez = c.hi[2] - c.lo[2];
+      const float area = ex * ey + ey * ez + ez * ex;
+      if (area > best) { best = area; pick = k; }
+    }
+    if (pick < 0) break;
+    const uint32_t l = bin[cand[pick]].leftFirst;
+    for (int k = nc; k > pick + 1; --k) cand[k] = cand[k - 1];      // the two children take the place of their parent
+    cand[pick] = l; cand[pick + 1] = l + 1;
+    ++nc;
+  }
+  return nc;
+}
+int fill_group(const std::vector<BvhNode>& bin, uint32_t b, std::vector<BvhNode>& q, uint32_t g, uint32_t depth, BvhBuildResult* out,
+               uint32_t cand[4]) {
+  const int nc = group_candidates(bin, b, cand);
   out->quad_depth = std::max(out->quad_depth, depth);
   for (int k = 0; k < 4; ++k) {
     BvhNode s;
@@ -272,7 +300,16 @@ uint32_t collapse_node(const std::vector<BvhNode>& bin, uint32_t b, std::vector<
 }
 }  // namespace
 
+static void collapse_once(BvhBuildResult* out);
 void collapse_to_quads(BvhBuildResult* out) {
+  static const bool fixed = [] { const char* e = std::getenv("RTX_COLLAPSE"); return e && std::strcmp(e, "fixed") == 0; }();   // tuning hook
+  g_greedy_collapse = !fixed;
+  collapse_once(out);
+  // the traversal stack holds 3 entries per group level (rtx.hip checks 3 * quad_depth): a tree the greedy choice
+  // makes too deep in groups is collapsed two binary levels per group instead
+  if (g_greedy_collapse && 3 * out->quad_depth > 48) { g_greedy_collapse = false; collapse_once(out); g_greedy_collapse = true; }
+}
+static void collapse_once(BvhBuildResult* out) {
   out->quads.clear(); out->quad_depth = 0; out->quad_slots = 0;
   for (uint32_t& t : out->top_groups) t = 0;
   const std::vector<BvhNode>& bin = out->nodes;
@@ -305,13 +342,8 @@ void collapse_to_quads(BvhBuildResult* out) {
     // the groups of the deepest top level: their internal slots (candidates recomputed as fill_group found them)
     for (const Item& it : fifo) {
       if (it.depth < (uint32_t)kTopLevels) continue;
-      uint32_t cand[4]; int nc = 0;
-      const uint32_t kids[2] = {bin[it.bin_node].leftFirst, bin[it.bin_node].leftFirst + 1};
-      for (int k = 0; k < 2; ++k) {
-        const BvhNode& c = bin[kids[k]];
-        if (c.count == 0) { cand[nc++] = c.leftFirst; cand[nc++] = c.leftFirst + 1; }
-        else cand[nc++] = kids[k];
-      }
+      uint32_t cand[4];
+      const int nc = group_candidates(bin, it.bin_node, cand);
       for (int k = 0; k < nc; ++k)
         if (bin[cand[k]].count == 0) {
           const uint32_t child = collapse_node(bin, cand[k], q, it.depth + 1, out);

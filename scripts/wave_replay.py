@@ -54,6 +54,12 @@ def main():
     policies = {"groups (64, no refill)": (64, 1, 0), "refill16 defer24 (before)": (16, 24, 0), "refill16 defer1": (16, 1, 0)}
     policies["refill16 defer24 block8 spec1 (tree)"] = (16, 24, 1, 8)
     policies["refill16 defer24 block8 spec1 one-tri (tree, split)"] = (16, 24, 1, 8, 1)
+    if os.environ.get("REPLAY_MORE"):          # policy studies: refill threshold, pending slots, leaf-phase thresholds
+        policies = {"groups (64, no refill)": (64, 1, 0), "refill16 defer24 block8 spec1 split (tree r1)": (16, 24, 1, 8, 1)}
+        for rf in (8, 4):
+            policies["refill%d defer24 block8 spec1 split" % rf] = (rf, 24, 1, 8, 1)
+        for sp, df, bl in ((2, 24, 8), (2, 32, 8), (2, 40, 12), (2, 48, 16), (3, 40, 12), (3, 48, 16), (4, 48, 16)):
+            policies["refill8 defer%d block%d spec%d split" % (df, bl, sp)] = (8, df, sp, bl, 1)
     acc = {k: np.zeros(8) for k in policies}
     for w in range(nwaves):
         os_, ds_ = [], []
