@@ -958,10 +958,10 @@ static int launch_trace_queue(rtx_scene* s, const float4* rays, const uint32_t* 
                               bool shadow = false, bool any_blocker = false, bool side = false) {
   hipStream_t on = side ? ws(s).stream2 : ws(s).stream;                        // side launches have their own overflow columns
   uint32_t* ovf = (side ? ws(s).w_stack_ovf2 : ws(s).w_stack_ovf).as<uint32_t>();
-  const uint32_t grid = trace_blocks(s, (bound * stride + kBlock - 1) / kBlock);
+  const uint32_t grid = trace_blocks(s, ((bound + 63) / 64 * 64 * stride + kBlock - 1) / kBlock);
   const uint32_t grid_r = std::min<uint32_t>(grid, (uint32_t)s->ncu * RTX_BLOCKS_REFILL);
   const int mode = sched_pick(s, shadow ? KIND_SHADOW : KIND_BOUNCE, bound * stride);
-  const uint32_t bounded = shadow ? (any_blocker ? 3u : 1u) : 0u;
+  const uint32_t bounded = shadow ? ((any_blocker ? 3u : 1u) | 4u) : 0u;      // 4: the queue is in shadow_index order
   if (mode != SCHED_GROUPS)
     hipLaunchKernelGGL(k_trace_queue<true>, dim3(grid_r), dim3(kBlock), 0, on, s->dev, rays, count, stride, bounded, grab_size(),
                        mode == SCHED_REFILL_SPLIT ? kTriMinSplit : 1u, ovf, hits);
@@ -1266,13 +1266,14 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
   const int max_gen = (shade && any_child) ? std::max(0, opt->max_bounces - pr.bounce0) : 0;
   const uint64_t max_nodes = tree ? ((uint64_t)pr.n0 << max_gen) : pr.n0;
   // ray indices are 32-bit in the kernels and a wave's next unit may lie up to one grid of units past the end
-  if (max_nodes * std::max<uint64_t>(std::max(NLS, G), 1) >= (1ull << 31)) return fail(RTX_ELIMIT, "ray queue would exceed 2^31 entries");
+  if ((max_nodes + 64) * std::max<uint64_t>(std::max(NLS, G), 1) >= (1ull << 31)) return fail(RTX_ELIMIT, "ray queue would exceed 2^31 entries");
   if (int rc = ws(s).w_hits[0].ensure((size_t)pr.n0 * 8)) return rc;
   if (shade) {
     if (int rc = ws(s).w_parents.ensure((size_t)max_nodes * 4)) return rc;
     if (opt->shadows) {
-      if (int rc = ws(s).w_shadow_rays.ensure((size_t)max_nodes * NLS * 32)) return rc;
-      if (int rc = ws(s).w_shadow_hits.ensure((size_t)max_nodes * NLS * 8)) return rc;
+      const size_t tiled = ((size_t)max_nodes + 63) / 64 * 64;          // shadow_index layout: whole groups of 64 parents
+      if (int rc = ws(s).w_shadow_rays.ensure(tiled * NLS * 32)) return rc;
+      if (int rc = ws(s).w_shadow_hits.ensure(tiled * NLS * 8)) return rc;
     }
     if (G) {
       if (int rc = ws(s).w_gi_rays.ensure((size_t)max_nodes * G * 32)) return rc;

@@ -490,8 +490,17 @@ struct CameraSource {
   __device__ __forceinline__ bool first_hit_decides() const { return false; }
   __device__ __forceinline__ float tmax_of(uint32_t) const { return INFINITY; }
 };
+// Shadow rays of a node with several light samples: ray (parent p, sample ls) lives at shadow_index(p, ls, NLS) --
+// light-major within groups of 64 parents, so that the 64 rays of a wave unit go from 64 neighbouring hit points to
+// ONE light (parent-major, a unit would be 4 hit points x 16 lights: 16 directions in one wave).  The queue then
+// spans roundup64(parents) * NLS entries, of which those of parents beyond the count hold nothing.
+__device__ __forceinline__ size_t shadow_index(uint32_t parent, uint32_t ls, uint32_t nls) {
+  return (size_t)(parent >> 6) * 64u * nls + (size_t)ls * 64u + (parent & 63u);
+}
 struct QueueSource {
   const float4* rays;
+  uint32_t tile_stride = 0;   // != 0: shadow_index layout with this many samples per parent, nparents parents
+  uint32_t nparents = 0;
   uint32_t bounded;    // rd.w of the records is tmax (shadow queue) rather than a throughput
   uint32_t anyhit;     // shadow queue of a scene whose materials all shade a blocked light alike: any
                        // hit clearly before the light gives canSeeLight's answer *and* colour, so the
@@ -499,6 +508,7 @@ struct QueueSource {
   __device__ __forceinline__ bool first_hit_decides() const { return anyhit != 0; }
   __device__ __forceinline__ float tmax_of(uint32_t slot) const { return rays[2 * (size_t)slot + 1].w; }
   __device__ __forceinline__ bool get(uint32_t j, V3* o, V3* d1, uint32_t* slot, float* tmax) const {
+    if (tile_stride != 0 && (j / (64u * tile_stride)) * 64u + (j & 63u) >= nparents) return false;
     const float4 ro = rays[2 * (size_t)j], rd = rays[2 * (size_t)j + 1];
     *o = v3(ro.x, ro.y, ro.z); *d1 = v3(rd.x, rd.y, rd.z); *slot = j;
     *tmax = bounded ? rd.w : INFINITY;
@@ -826,11 +836,14 @@ __global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_tra
                                                          uint32_t bounded, uint32_t grab, uint32_t tri_min, uint32_t* ovf, uint2* hits) {
   __shared__ uint32_t lds_stack[(kRefill ? kLdsStack : kLdsStackGroups) * kBlock];
   QueueSource src; src.rays = rays; src.bounded = bounded; src.anyhit = ((bounded & 2u) && (S.flags & 2u)) ? 1u : 0u;
+  const uint32_t cnt = *count;
+  uint32_t n = cnt * stride;
+  if (bounded & 4u) { src.tile_stride = stride; src.nparents = cnt; n = ((cnt + 63u) & ~63u) * stride; }   // shadow_index layout
   constexpr int kTop = kRefill ? kTopGroupsRefill : kTopGroups;
   __shared__ uint4 lds_top[kTop > 0 ? 4 * kTop : 1];
   const TopLevels<kTop> top = load_top_levels<kTop>(S, lds_top);
   __shared__ uint32_t lds_ctr;
-  const Work work = make_work(*count * stride, grab, &lds_ctr);
+  const Work work = make_work(n, grab, &lds_ctr);
   if constexpr (kRefill) {
     __shared__ uint32_t lds_wbuf[(kBlock / 64) * kWbufWords * 64];
     trace_wave(S, top, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), tri_min, hits);
@@ -1247,7 +1260,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(PipeArgs A) {
         const V3 L = light_sample(A, sf.P, ls, &fifth);
         // canSeeLight: Ray(position, toLight.normalized()) normalises twice (src/flyscene.cpp:749-750)
         const V3 d1s = normalized(normalized(L - sf.P));
-        const size_t k = (size_t)slot * NLS + ls;
+        const size_t k = shadow_index(slot, ls, NLS);
         A.shadow_rays[2 * k] = make_float4(sf.P.x, sf.P.y, sf.P.z, 0.0f);
         A.shadow_rays[2 * k + 1] = make_float4(d1s.x, d1s.y, d1s.z, shadow_tmax(L, sf.P));
       }
@@ -1347,7 +1360,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(PipeArgs A) {
       const float dotted = dot(eye, normalized(reflectedLight));
       bool visible = true; int bmat = -1;
       if (A.shadows) {
-        const size_t k = (size_t)h * NLS + ls;
+        const size_t k = shadow_index(h, ls, NLS);
         const float4 sd = A.shadow_rays[2 * k + 1];
         const uint2 sh = A.shadow_hits[k];
         visible = can_see_light(A.S, light, sf.P, v3(sd.x, sd.y, sd.z), __uint_as_float(sh.x), (int)sh.y, &bmat);
