@@ -17,7 +17,7 @@ def api():
 
 
 def _cams(api, fx, W, H):
-    return [api.make_camera(fx["view_default"], W, H), api.make_camera(fx["view_oblique"], W, H, subpixel=(0.25, 0.75)),
+    return [api.make_camera(fx["view_default"], W, H), api.make_camera(fx["view_oblique"], W, H, fovy=45.0, aspect=1.3, subpixel=(0.25, 0.75)),
             api.make_camera(fx["view_top"], W, H), api.make_camera(fx["view_oblique"], W, H),
             api.make_camera(fx["view_default"], W, H, subpixel=(0.5, 0.125))]
 
