@@ -291,7 +291,9 @@ int rtx_render_tiles_dev_enqueue(rtx_scene*, const rtx_camera*, const rtx_option
  * with that camera, bit for bit.  For the ranks of an N-GPU run: a rank's share of one frame gives its persistent
  * traversal kernels too few rays to run at full rate (1/8 of the 4K soup frame: 0.37 ms instead of 0.23 ms), its
  * share of N frames of an animation gives them as many as one whole frame.  The enqueue form is finished by
- * rtx_render_finish like the others; rtx_stats counts the rays of all frames of the batch.
+ * rtx_render_finish like the others; rtx_stats counts the rays of all frames of the batch.  Workspace: the call's queues are
+ * sized for all frames at once -- about 8 + 4 + 40 L bytes per pixel and frame (hit records, parents, L light samples' shadow rays
+ * and hits), more with bounces -- per call slot in use: 3.4 GB for 8 frames of 3840x2160 with one light.
  * No counterpart in the reference (raytraceScene renders one camera, src/flyscene.cpp:395-468). */
 #define RTX_MAX_BATCH 16
 int rtx_render_tiles_batch_dev(rtx_scene*, const rtx_camera* cams, int32_t nframes, const rtx_options*, rtx_rect rect,
