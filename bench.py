@@ -133,8 +133,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=6144, help="primary rays in the cpu_baseline sample")
     ap.add_argument("--roofline-stride", type=int, default=16, help="every k-th pixel feeds the byte count")
     ap.add_argument("--no-scaling-proxy", action="store_true")
-    ap.add_argument("--inflight", type=int, default=2, choices=[1, 2, 3, 4],
-                    help="render calls in flight (rtx_render_*_enqueue): they run side by side on the GPU, each on its own streams")
+    ap.add_argument("--inflight", type=int, default=None, choices=[1, 2, 3, 4],
+                    help="render calls in flight (rtx_render_*_enqueue): they run side by side on the GPU, each on its own streams; "
+                         "default 2 for batches of frames, 4 for the passes of a frame with several samples per pixel (measured)")
     ap.add_argument("--batch", type=int, default=8,
                     help="frames per render call (rtx_render_tiles_batch_dev_enqueue, 1-16): one set of launches traces them all")
     args = ap.parse_args()
@@ -185,6 +186,8 @@ def main():
     npix_local = kmax * TILE * TILE if world > 1 else W * H
     pipelined = len(cams) == 1
     B = max(1, min(args.batch, api.MAX_BATCH)) if pipelined else 1
+    if args.inflight is None:
+        args.inflight = 2 if pipelined else 4
     # Three sets of output buffers: the render of frame k+1 (librtx's own stream) overlaps the gather
     # and reassembly of frame k (torch's streams); a set is reused only after the torch work that
     # read it has finished (event per set).
@@ -226,41 +229,47 @@ def main():
             return (b["img"][nf - 1], None)
         return None
 
+    spp_rgb = [torch.zeros((npix_local, 3), dtype=torch.float32, device=dev) for _ in cams] if len(cams) > 1 else None
+
     def frame():
-        """One frame: render my tiles (all spp passes), gather to rank 0, assemble."""
+        """One frame of several samples per pixel: the passes (one camera per sub-pixel offset) are enqueued side by side,
+        each into a buffer of its own, then summed in pass order and averaged; gather to rank 0, assemble."""
         b = sets[state["k"] % NSETS]
         state["k"] += 1
-        rgb, face, acc = b["rgb"], b["face"], b["acc"]
+        face, acc = b["face"], b["acc"]
         rays = [0, 0, 0]
         ms = [0.0, 0.0, 0.0]
         b["free"].synchronize()            # torch is done with this set (frame k - 2)
-        if acc is not None:
-            acc.zero_()
-        for cam in cams:
-            if acc is not None:
-                # librtx runs on its own HIP stream: the accumulation that reads rgb must be done first
-                torch.cuda.current_stream().synchronize()
-            if world > 1:
-                scene.render_tiles_dev(cam, opts, rect, TILE, rank, world, rgb.data_ptr(), None, face.data_ptr())
-            else:
-                scene.render_dev(cam, opts, rect, rgb.data_ptr(), None, face.data_ptr())
-            st = scene.stats()
+        torch.cuda.current_stream().synchronize()       # ... and with the pass buffers (the sum of the frame before)
+
+        def finish_one():
+            st = scene.render_finish()
             rays[0] += st.rays_primary
             rays[1] += st.rays_shadow
             rays[2] += st.rays_reflection
             ms[0] += st.ms_trace_camera
             ms[1] += st.ms_trace - st.ms_trace_camera
             ms[2] += st.ms_total
-            if acc is not None:
-                acc.add_(rgb)
-        out = rgb if acc is None else acc.mul_(1.0 / len(cams))
+        flying = 0
+        for k, cam in enumerate(cams):
+            if world > 1:
+                scene.render_tiles_dev_enqueue(cam, opts, rect, TILE, rank, world, spp_rgb[k].data_ptr(), None, face.data_ptr() if k == 0 else None)
+            else:
+                scene.render_dev_enqueue(cam, opts, rect, spp_rgb[k].data_ptr(), None, face.data_ptr() if k == 0 else None)
+            flying += 1
+            if flying >= args.inflight:
+                finish_one()
+                flying -= 1
+        for _ in range(flying):
+            finish_one()
+        acc.zero_()
+        for k in range(len(cams)):
+            acc.add_(spp_rgb[k])
+        out = acc.mul_(1.0 / len(cams))
         img = exchange(b, out, face)
         b["free"].record()
         return rays, ms, img
 
-    # One sample per pixel: frames go through the enqueue / finish entry points, frame k+1 queued before
-    # frame k is waited for (and, with several ranks, gathered), so the GPU does not idle while the host
-    # finishes a frame.  Several samples per pixel are accumulated by torch between passes: synchronous.
     # Frames of a sequence go to the library B at a time (one camera per frame -- the same one here, the library
     # does not know that): one set of launches traces and shades the rank's tiles of all B frames.
     def batch_enqueue(nf):
@@ -359,8 +368,9 @@ def main():
                        "triangles_outside_bvh": int(info.nwild),
                        "image": [W, H], "lights": len(wl["lights"]), "spp": wl["spp"], "max_bounces": wl["opts"][0],
                        "tile": TILE, "partition": (("image tiles round-robin over %d ranks, scene replicated, RGB gathered to rank 0" % world) if world > 1
-                                     else "one rank renders the whole frame row-major") + (("; %d frames per render call (rtx_render_tiles_batch_dev_enqueue), %d calls in flight" % (B, args.inflight)) if pipelined else ""),
-                       "frames_per_call": B, "calls_in_flight": args.inflight if pipelined else 1,
+                                     else "one rank renders the whole frame row-major") + (("; %d frames per render call (rtx_render_tiles_batch_dev_enqueue), %d calls in flight" % (B, args.inflight)) if pipelined
+                                        else "; %d passes per frame (one per sub-pixel sample), %d in flight, summed in pass order" % (len(cams), args.inflight)),
+                       "frames_per_call": B, "calls_in_flight": args.inflight,
                        "rays_per_frame": {"primary": int(agg[0].item() / args.steps), "shadow": int(agg[1].item() / args.steps),
                                           "reflection": int(agg[2].item() / args.steps)},
                        "pixels_hitting_geometry": hits,
