@@ -161,6 +161,39 @@ def main():
         opts = (int(rng.integers(0, 3)), refl, refr, gi, 1, int(rng.integers(0, 2)))     # the last: do not trace children of weight 0
         s.commit(0)
         rgb, tt, ff = s.render(api.make_camera(view, res, res), api.Options(*opts), (0, 0, res, res))
+        # the same frame and a second view as ONE batch (rtx_render_tiles_batch_dev), whole or as one part of a tile
+        # partition: every frame of the batch must be the single call's, bit for bit
+        import torch
+        view2 = scenes.look_at_view(tuple(rng.uniform(-1, 1, 3) * 2.5 * ext + np.float64([0, 0, 0.5 * ext])), tuple(rng.uniform(-.2, .2, 3) * ext))
+        rgb2, tt2, ff2 = s.render(api.make_camera(view2, res, res), api.Options(*opts), (0, 0, res, res))
+        ts, nparts = [(0, 1), (16, 1), (16, 3), (32, 2)][int(rng.integers(0, 4))]
+        part = int(rng.integers(0, nparts))
+        P = res * res if ts == 0 else api.lib().rtx_tiles_count(api.Rect(0, 0, res, res), ts, part, nparts) * ts * ts
+        if P:
+            cams = [api.make_camera(view, res, res), api.make_camera(view2, res, res), api.make_camera(view, res, res)]
+            b_rgb = torch.zeros((3 * P, 3), dtype=torch.float32, device="cuda")
+            b_t = torch.zeros((3 * P,), dtype=torch.float32, device="cuda")
+            b_f = torch.full((3 * P,), -9, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            s.render_tiles_batch_dev(cams, api.Options(*opts), (0, 0, res, res), ts, part, nparts, b_rgb.data_ptr(), b_t.data_ptr(), b_f.data_ptr())
+            b_rgb, b_t, b_f = b_rgb.cpu().numpy().reshape(3, P, 3), b_t.cpu().numpy().reshape(3, P), b_f.cpu().numpy().reshape(3, P)
+            for f, (wr, wt, wf) in enumerate(((rgb, tt, ff), (rgb2, tt2, ff2), (rgb, tt, ff))):
+                if ts == 0:
+                    sel_y, sel_x = np.divmod(np.arange(P), res)
+                    live = np.ones(P, bool)
+                else:
+                    tx = (res + ts - 1) // ts
+                    k, within = np.divmod(np.arange(P), ts * ts)
+                    g = k * nparts + part
+                    sel_y = (g // tx) * ts + within // ts
+                    sel_x = (g % tx) * ts + within % ts
+                    live = (sel_x < res) & (sel_y < res)
+                sy, sx = sel_y[live], sel_x[live]
+                same = (np.array_equal(b_f[f][live], wf[sy, sx]) and np.array_equal(b_t[f][live].view(np.uint32), wt[sy, sx].view(np.uint32))
+                        and np.array_equal(b_rgb[f][live].view(np.uint32), wr[sy, sx].view(np.uint32)))
+                if not same:
+                    print("seed %d: frame %d of a batch differs from its single call (tile %d, part %d of %d, options %r)" % (seed, f, ts, part, nparts, opts))
+                    sys.exit(1)
         s.close()
         o_scene.set_options(*opts)
         orgb, ot, of = o_scene.render(oa.make_camera(view, res, res), (0, 0, res, res), threads=16)
