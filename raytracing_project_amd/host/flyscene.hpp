@@ -546,6 +546,16 @@ class Flyscene {
     rtx_check(rtx_trace_shade(scene, &options, o.v, d.v, 1, bounce, insideObject ? 1 : 0, c.v));
     return c;
   }
+  // src/flyscene.cpp:603-629: the colour of an already found hit, summed over the lights.  The reference only ever calls it
+  // with the (hit, face) that getIntersections(ray) has just returned (:588-594), and for that pair it is traceRay's value:
+  // this forwards to traceRay, and refuses a hit that is not the ray's own closest hit (calculateColor, its per-light term,
+  // takes intermediate state of that sum and has no entry point of its own: call traceRay / Shader).
+  Vector3f Shader(int bounce, Tucano::Face /*face*/, HitInfo hit, Ray ray, bool insideObject) {
+    const std::pair<HitInfo, Tucano::Face> own = getIntersections(ray);
+    if (own.first.faceId != hit.faceId || std::memcmp(&own.first.t, &hit.t, 4) != 0)
+      throw RtxError(RTX_EINVAL, "rtx: Shader() takes the hit getIntersections() returns for the same ray");
+    return traceRay(bounce, ray, insideObject);
+  }
   // src/flyscene.cpp:517-585
   std::pair<HitInfo, Tucano::Face> getIntersections(Ray ray) {
     sync();

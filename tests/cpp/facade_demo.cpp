@@ -3,6 +3,7 @@
 // to compare with the oracle.  usage: facade_demo <model.obj> <width> <rays.txt>
 // rays.txt: lines "ox oy oz dx dy dz".
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <fstream>
 
@@ -37,6 +38,14 @@ int main(int argc, char** argv) {
       }
       Vector3f col = fs.traceRay(0, r, false);
       std::printf("rgb %.9g %.9g %.9g\n", col[0], col[1], col[2]);
+      if (hit.first.t != INFINITY) {          // Flyscene::Shader by name: traceRay's value for the ray's own hit, refused for another
+        Vector3f sh = fs.Shader(0, hit.second, hit.first, r, false);
+        if (std::memcmp(sh.v, col.v, 12) != 0) { std::printf("Shader() differs from traceRay()\n"); return 1; }
+        HitInfo other = hit.first; other.faceId += 1;
+        bool refused = false;
+        try { fs.Shader(0, hit.second, other, r, false); } catch (const RtxError&) { refused = true; }
+        if (!refused) { std::printf("Shader() accepted a hit that is not the ray's\n"); return 1; }
+      }
     }
     // the primitive classes and the GI probe by name (src/Intersect.h:8-89, src/flyscene.cpp:631-669), first rays again
     std::printf("boxes %zu", fs.boxes.size());
