@@ -159,6 +159,15 @@ def main():
             else:
                 assert o_scene.build_leafboxes() == nl
         opts = (int(rng.integers(0, 3)), refl, refr, gi, 1, int(rng.integers(0, 2)))     # the last: do not trace children of weight 0
+        # the oracle's render is a brute-force scan per ray on the CPU: keep a frame's cost (triangles x pixels x tree nodes x rays per
+        # node) below a few minutes of host time, or the run looks hung (seed 980246: 96^2 pixels, a two-bounce tree, 30 k triangles)
+        def cost(res_, opts_):
+            nodes_ = (2 ** (opts_[0] + 1) - 1) if (refl and refr) else (opts_[0] + 1 if (refl or refr) else 1)
+            return float(len(T)) * res_ * res_ * nodes_ * (1 + len(lights) + (5 if slights is not None else 0))
+        if cost(res, opts) > 6e9:
+            res = 48
+        while cost(res, opts) > 6e9 and opts[0] > 0:
+            opts = (opts[0] - 1,) + opts[1:]
         s.commit(0)
         rgb, tt, ff = s.render(api.make_camera(view, res, res), api.Options(*opts), (0, 0, res, res))
         # the same frame and a second view as ONE batch (rtx_render_tiles_batch_dev), whole or as one part of a tile
