@@ -272,21 +272,31 @@ def main():
 
     # Frames of a sequence go to the library B at a time (one camera per frame -- the same one here, the library
     # does not know that): one set of launches traces and shades the rank's tiles of all B frames.
+    host = {"wait_buffers": 0.0, "enqueue": 0.0, "wait_render": 0.0, "exchange": 0.0}    # where rank 0's host time goes (seconds)
+
     def batch_enqueue(nf):
         b = sets[state["k"] % NSETS]
         state["k"] += 1
+        t_a = time.perf_counter()
         b["free"].synchronize()
+        t_b = time.perf_counter()
+        host["wait_buffers"] += t_b - t_a
         b["nf"] = nf
         scene.render_tiles_batch_dev([cams[0]] * nf, opts, rect, TILE if world > 1 else 0, rank if world > 1 else 0, world,
                                      b["rgb"].data_ptr(), None, b["face"].data_ptr(), enqueue=True)
+        host["enqueue"] += time.perf_counter() - t_b
         return b
 
     def batch_finish(b):
+        t_a = time.perf_counter()
         st = scene.render_finish()
+        t_b = time.perf_counter()
+        host["wait_render"] += t_b - t_a
         rays = [st.rays_primary, st.rays_shadow, st.rays_reflection]
         ms = [st.ms_trace_camera, st.ms_trace - st.ms_trace_camera, st.ms_total]
         img = exchange(b, b["rgb"], b["face"], b["nf"])
         b["free"].record()
+        host["exchange"] += time.perf_counter() - t_b
         return rays, ms, img
 
     def frames(n):
@@ -319,6 +329,8 @@ def main():
     frames(7 * B)
     frames(args.warmup)
     sync()
+    for k in host:
+        host[k] = 0.0
     t0 = time.perf_counter()
     rays_tot = np.zeros(3, np.int64)
     ms_tot = np.zeros(3, np.float64)
@@ -326,8 +338,11 @@ def main():
     for r, m, img in frames(args.steps):
         rays_tot += r
         ms_tot += m
+    t_loop = time.perf_counter() - t0
     sync()
     dt = time.perf_counter() - t0
+    host_ms = {k: v / args.steps * 1e3 for k, v in host.items()}
+    host_ms["final_sync"] = (dt - t_loop) / args.steps * 1e3
     # whole-job aggregates: rays summed over ranks, time = max over ranks
     agg = torch.tensor([float(rays_tot[0]), float(rays_tot[1]), float(rays_tot[2])], dtype=torch.float64, device="cpu" if rehearse else dev)
     tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
@@ -374,6 +389,9 @@ def main():
                        "rays_per_frame": {"primary": int(agg[0].item() / args.steps), "shadow": int(agg[1].item() / args.steps),
                                           "reflection": int(agg[2].item() / args.steps)},
                        "pixels_hitting_geometry": hits,
+                       # rank 0's host thread, ms per frame of the timed region: waiting for a free buffer set (torch still gathering /
+                       # reassembling an earlier call), enqueueing, waiting for the render, issuing gather + reassembly, the last sync
+                       "host_ms_per_frame_rank0": host_ms,
                        # spans of the timed region: with several frames in flight they overlap each other
                        "kernel_span_ms_per_frame_rank0": {"trace_camera": ms_tot[0] / args.steps,
                                                            "trace_queue": ms_tot[1] / args.steps,
