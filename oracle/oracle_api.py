@@ -204,8 +204,43 @@ def ref():
         R.ref_refract.argtypes = [_f, _f, _f, _f, _f, C.c_float, C.c_float, _f, _f]
         R.ref_resend.argtypes = [_f, _f, _f, _f, C.c_int, _f]
         R.ref_camera.argtypes = [_f, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _f, _f]
+        if hasattr(R, "ref_load_mtl"):      # (a libref.so built before these doors existed lacks them)
+            R.ref_load_mtl.argtypes = [C.c_char_p, _f, C.c_char_p, C.c_int]
+            R.ref_load_mtl.restype = C.c_int
+            R.ref_write_ppm.argtypes = [C.c_char_p, _f, C.c_int, C.c_int]
+            R.ref_write_ppm.restype = None
+            R.ref_default_mtl.argtypes = [_f]
+            R.ref_default_mtl.restype = None
         _ref = R
     return _ref
+
+
+def ref_load_mtl(path, cap=64):
+    """Tucano::MaterialImporter::loadMTL run by the reference build: (names, float32 [n, 13] = ka kd ks ns ni d illum)."""
+    R = ref()
+    vals = np.zeros((cap, 13), np.float32)
+    names = C.create_string_buffer(64 * cap)
+    n = R.ref_load_mtl(str(path).encode(), fp(vals), names, cap)
+    if n < 0:
+        return None, None
+    assert n <= cap
+    return [names.raw[64 * i: 64 * i + 64].split(b"\0")[0].decode("latin-1") for i in range(n)], vals[:n].copy()
+
+
+def ref_default_mtl():
+    v = np.zeros(13, np.float32)
+    ref().ref_default_mtl(fp(v))
+    return v
+
+
+def ref_write_ppm(path, frame):
+    """Tucano::ImageImporter::writePPMImage run by the reference build on a SQUARE row-major frame [y][x][3], handed
+    over the way raytraceScene does: pixel (x, y) at data[x][y] (src/flyscene.cpp:465)."""
+    frame = np.ascontiguousarray(frame, np.float32)
+    h, w, _ = frame.shape
+    assert h == w, "the reference's writer is only defined for square frames (SURVEY F8)"
+    data = np.ascontiguousarray(frame.transpose(1, 0, 2))      # data[x][y]
+    ref().ref_write_ppm(str(path).encode(), fp(data), w, h)
 
 
 def make_mtl(ka=(0.3, 0.3, 0.3), kd=(0.5, 0.5, 0.5), ks=(1.0, 1.0, 1.0), ns=10.0, ni=0.0, d=1.0, illum=0):

@@ -8,6 +8,8 @@
 //   * Eigen 3.3.7 (vendored)     normalized / cross / Affine inverse, as used by
 //                                tucano/mesh.hpp:461-463 and src/flyscene.cpp:839
 //   * src/box.h                  Box(tmin, tmax), Box::isInBox
+//   * tucano/utils/mtlIO.hpp     Tucano::MaterialImporter::loadMTL, tucano/materials/mtl.hpp Mtl() defaults
+//   * tucano/utils/ppmIO.hpp     Tucano::ImageImporter::writePPMImage(string, vector<vector<Vector3f>>)
 // Box(Tucano::Mesh) / Mesh::createFaces (src/box.h:41-85, tucano/mesh.hpp:441-468) were tried too: a Tucano::Mesh
 // cannot be constructed without an OpenGL context and library -- the probe links with __glewGenVertexArrays,
 // __glewBindVertexArray, __glewDeleteVertexArrays, __glewBindBuffer, __glew{Enable,Disable}VertexAttribArray,
@@ -18,11 +20,25 @@
 // image), so the drivers above these primitives (getIntersections, traceRay,
 // calculateColor ...) are validated through oracle/rt_oracle.c, whose primitive
 // arithmetic is pinned bit-for-bit against this library.
+// Tucano::Flycamera (utils/flycamera.hpp:76-86,166-191) was tried as well: its member Tucano::Shapes::CoordinateAxes is a
+// Mesh + Shader, and the probe has 26 undefined GL symbols (__glewGenVertexArrays ... glGetError): not loadable, no stand-ins,
+// so the default view [I | (0,0,-2)] stays pinned by SURVEY F12 and by ref_camera's getCenter() = (0,0,2) for that matrix.
 #include <cmath>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
 #include <vector>
 #include <iostream>
+#include <Eigen/Dense>
+using namespace std;            // the Tucano headers below name vector / string / ifstream unqualified (their own includers do this)
+// mtlIO.hpp comes first: tucano/shader.hpp (pulled in by camera.hpp / texture.hpp) #defines TUCANODEBUG, which adds a
+// GL error poll (glGetError) at the end of loadMTL -- the parse itself is the same either way, but the library would
+// not load here.  Included before that macro exists, loadMTL is the reference's parser and nothing else.
+#include <tucano/utils/mtlIO.hpp>
 #include "Intersect.h"          // reference src/Intersect.h (pulls Ray.h, hitInfo.h, box.h)
 #include <tucano/camera.hpp>    // reference dependencies/tucano
+#include <tucano/utils/ppmIO.hpp>
 
 using Eigen::Vector3f;
 static inline Vector3f V(const float* p) { return Vector3f(p[0], p[1], p[2]); }
@@ -119,5 +135,32 @@ void ref_camera(const float* view, float vw, float vh, float fovy, float aspect,
   cam.setViewport(Eigen::Vector2f(vw, vh));
   S(world, cam.screenToWorld(Eigen::Vector2f(i, j)));
   S(center, cam.getCenter());
+}
+
+// Tucano::Material::Mtl as 13 floats: ka, kd, ks, shininess, optical density, dissolve, illumination model
+static void mtl_out(const Tucano::Material::Mtl& m, float* o) {
+  S(o, m.getAmbient()); S(o + 3, m.getDiffuse()); S(o + 6, m.getSpecular());
+  o[9] = m.getShininess(); o[10] = m.getOpticalDensity(); o[11] = m.getDissolveFactor(); o[12] = m.getIlluminationModel();
+}
+// Tucano::Material::Mtl()  (tucano/materials/mtl.hpp:21-39,49-51)
+void ref_default_mtl(float* out13) { Tucano::Material::Mtl m; mtl_out(m, out13); }
+// Tucano::MaterialImporter::loadMTL  (tucano/utils/mtlIO.hpp:45-125).  Returns the material count (-1: file not
+// opened); the first `cap` materials go to out13 (13 floats each) and names (64 bytes each, NUL padded).
+int ref_load_mtl(const char* path, float* out13, char* names64, int cap) {
+  std::vector<Tucano::Material::Mtl> mats;
+  if (!Tucano::MaterialImporter::loadMTL(mats, path)) return -1;
+  for (int i = 0; i < (int)mats.size() && i < cap; ++i) {
+    mtl_out(mats[i], out13 + 13 * i);
+    std::memset(names64 + 64 * i, 0, 64);
+    std::strncpy(names64 + 64 * i, mats[i].getName().c_str(), 63);
+  }
+  return (int)mats.size();
+}
+// Tucano::ImageImporter::writePPMImage(filename, vector<vector<Vector3f>>)  (tucano/utils/ppmIO.hpp:130-151), fed the
+// way Flyscene::raytraceScene feeds it (src/flyscene.cpp:408-411,433,465): data[a][b] = rgb[(a * n_inner + b) * 3 ..].
+void ref_write_ppm(const char* path, const float* rgb, int n_outer, int n_inner) {
+  std::vector<std::vector<Vector3f>> data(n_outer, std::vector<Vector3f>(n_inner));
+  for (int a = 0; a < n_outer; ++a) for (int b = 0; b < n_inner; ++b) data[a][b] = V(rgb + ((size_t)a * n_inner + b) * 3);
+  Tucano::ImageImporter::writePPMImage(path, data);
 }
 }  // extern "C"

@@ -6,6 +6,10 @@
                    (inputs) + closest-hit / shading dumps of the C oracle at 48x48 (outputs)
   scene_bunny.npz  resources/models/bunny.ply flattened by a numpy PLY reader (inputs) + the same dumps
   survey_observations.json  outputs of the unmodified reference recorded in SURVEY.md 8(c)
+  io_ref.json      the data formats either side of the path, run by the REFERENCE's own code (oracle/_ref):
+                   Tucano::MaterialImporter::loadMTL on every bundled .mtl (the file's text is the input) and on
+                   synthetic files with the tokeniser's corner cases, Tucano::Material::Mtl() defaults,
+                   Tucano::ImageImporter::writePPMImage on seeded square frames (inputs as float bits, output text)
 
 Usage: python tests/golden/make_golden.py
 """
@@ -205,8 +209,55 @@ def survey_observations():
     json.dump(obs, open(os.path.join(HERE, "survey_observations.json"), "w"), indent=1)
 
 
+SYNTHETIC_MTL = {
+    # std::getline(ss, s, ' ') tokens: doubled blanks give empty tokens (atof("") = 0), a trailing blank none
+    "double_blank": "newmtl a\nKa  0.1 0.2 0.3\nKd 1 0 0 \nNs  7\n",
+    "comments_and_unknown": "# header\n\nnewmtl m1\n# Kd 9 9 9\nTf 1 1 1\nKd 0.25 0.5 0.75\nmap_Kd x.png\nillum 2\nnewmtl m2\nd 0.5\nNi 1.45\n",
+    "crlf": "newmtl red\r\nKa 0.1 0.2 0.3\r\nKd 1 0 0\r\nNs 20\r\nd 0.25\r\n",
+    "tab_indented": "newmtl t\n\tKd 1 1 1\nKs 0.5 0.25 0.125\n",
+    "exponents": "newmtl e\nKa 1e-3 2.5E+1 -0.5\nNs 96.078431\nNi 1.000000\nd 1.000000\nillum 2\n",
+    "empty_file": "",
+    "only_comments": "# nothing here\n",
+}
+
+
+def io_pins(seed=20261112):
+    import tempfile
+    R = oa.ref()
+    assert R is not None and hasattr(R, "ref_load_mtl"), "oracle/_ref/libref.so missing or stale: make -C oracle"
+    bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32).tolist()
+    out = {"source": "oracle/_ref/libref.so = the reference's tucano/utils/mtlIO.hpp, materials/mtl.hpp, utils/ppmIO.hpp compiled in place "
+                     "(oracle/Makefile, oracle/ref_harness.cpp); floats are stored as their IEEE-754 bit patterns",
+           "default_mtl_bits": bits(oa.ref_default_mtl()), "mtl": {}, "ppm": []}
+    texts = {}
+    for f in sorted(os.listdir(MODELS)):
+        if f.endswith(".mtl"):
+            texts["bundled:" + f] = open(os.path.join(MODELS, f), newline="").read()
+    for k, v in SYNTHETIC_MTL.items():
+        texts["synthetic:" + k] = v
+    with tempfile.TemporaryDirectory() as tmp:
+        for key, text in texts.items():
+            path = os.path.join(tmp, "m.mtl")
+            with open(path, "w", newline="") as fh:
+                fh.write(text)
+            names, vals = oa.ref_load_mtl(path)
+            out["mtl"][key] = {"text": text, "names": names, "values_bits": bits(vals)}
+            print("mtl", key, names)
+        rng = np.random.default_rng(seed)
+        for n in (1, 2, 5, 16, 33):
+            rgb = (rng.random((n, n, 3)) * 1.4 - 0.2).astype(np.float32)          # below 0 and above 1 included
+            rgb.reshape(-1)[:: 7] = rng.choice(np.float32([0.0, 1.0, 0.999, 0.5, 254.5 / 255, 1.0 / 255, 0.00392, 2.0, -0.0]), rgb.reshape(-1)[:: 7].shape)
+            path = os.path.join(tmp, "o.ppm")
+            oa.ref_write_ppm(path, rgb)
+            out["ppm"].append({"n": n, "rgb_bits": bits(rgb.reshape(-1)), "text": open(path, newline="").read()})
+    json.dump(out, open(os.path.join(HERE, "io_ref.json"), "w"), indent=0)
+
+
 if __name__ == "__main__":
     oa.build(force=True)
+    if sys.argv[1:] == ["io"]:
+        io_pins()
+        sys.exit(0)
     if sys.argv[1:] == ["bunny"]:
         bunny_fixture()
         sys.exit(0)
@@ -216,3 +267,4 @@ if __name__ == "__main__":
     bunny_fixture()
     default_scene_with_spheres()
     survey_observations()
+    io_pins()

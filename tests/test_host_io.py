@@ -164,6 +164,39 @@ def test_ppm_writer_is_byte_identical_to_the_oracle_writer(tool, oa, tmp_path):
         assert open(tmp_path / "o.ppm", "rb").read() == open(tmp_path / "e.ppm", "rb").read()
 
 
+def test_facade_mtl_loader_and_ppm_writer_match_the_reference_executed_fixture(tool, tmp_path):
+    """tests/golden/io_ref.json = what the reference's OWN Tucano::MaterialImporter::loadMTL (mtlIO.hpp:45-125),
+    Tucano::Material::Mtl() (mtl.hpp:21-39) and Tucano::ImageImporter::writePPMImage (ppmIO.hpp:130-151) produced
+    (oracle/_ref, tests/golden/make_golden.py io).  The facade's loader and writer against them: values bit for bit,
+    file bytes equal."""
+    import json
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "io_ref.json")))
+    for key, rec in ref["mtl"].items():
+        with open(tmp_path / "m.mtl", "w", newline="") as fh:
+            fh.write(rec["text"])
+        # one face per material, named the way the file names it (CRLF files carry the \r in both places)
+        with open(tmp_path / "m.obj", "w", newline="") as fh:
+            fh.write("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\n" + "".join("usemtl %s\nf 1 2 3\n" % n for n in rec["names"] if n))
+        rc, err = run(tool, "obj", tmp_path / "m.obj", tmp_path / "d.bin")
+        assert rc == 0, err
+        _, _, tm, mats = read_dump(tmp_path / "d.bin")
+        want = np.array(rec["values_bits"], np.uint32).reshape(-1, 13).view(np.float32)
+        assert len(mats) == len(want), key
+        for m, w in zip(mats, want):
+            got = np.float32([*m[0], *m[1], *m[2], m[3], m[4], m[5], float(m[6])])
+            assert np.array_equal(got.view(np.uint32), w.view(np.uint32)), key
+        named = [n for n in rec["names"] if n]
+        # (several materials of one name: the importer keeps searching and the last match wins, objimporter.hpp:145-151)
+        assert tm.tolist() == [max(i for i, x in enumerate(rec["names"]) if x == n) for n in named], key
+    for rec in ref["ppm"]:
+        n = rec["n"]
+        with open(tmp_path / "i.bin", "wb") as f:
+            f.write(struct.pack("<2i", n, n)); f.write(np.array(rec["rgb_bits"], np.uint32).tobytes())
+        rc, err = run(tool, "ppm", tmp_path / "i.bin", tmp_path / "o.ppm")
+        assert rc == 0, err
+        assert open(tmp_path / "o.ppm", newline="").read() == rec["text"], n
+
+
 def test_facade_ray_value_type_matches_the_reference_goldens(tool, tmp_path):
     """Ray ctor, reflectRay, refractRay, resendRay of the facade's Ray (plain host arithmetic, like the reference's
     header-only src/Ray.h:7-58) against tests/golden/primitives.npz -- outputs of the reference's own Ray.h built with

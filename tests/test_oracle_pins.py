@@ -204,3 +204,79 @@ def test_ppm_writer(oa, tmp_path):
     p = str(tmp_path / "o.ppm")
     assert oa.lib().ora_ppm_write(p.encode(), fp(rgb), 2, 2, 0) == 0
     assert open(p).read() == "P3\n2 2\n255\n0 0 0 255 127 254 \n255 0 63 0 0 0 \n"
+
+
+# ---------------------------------------------------------------- the data formats either side of the path
+# tests/golden/io_ref.json holds what the reference's OWN loadMTL / Mtl() / writePPMImage gave (oracle/_ref, generated by
+# tests/golden/make_golden.py io): the oracle's restatements (oracle/rt_oracle_io.c) must reproduce them bit for bit.
+@pytest.fixture(scope="module")
+def io_ref():
+    return json.load(open(os.path.join(GOLDEN, "io_ref.json")))
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _oracle_mtl(oa, text, tmp_path):
+    with open(tmp_path / "m.mtl", "w", newline="") as fh:
+        fh.write(text)
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\n")
+    _, _, _, mats, names = oa.obj_load(str(tmp_path / "m.obj"))
+    vals = np.array([[*m.ka, *m.kd, *m.ks, m.ns, m.ni, m.d, float(m.illum)] for m in mats], np.float32).reshape(-1, 13)
+    return names, vals
+
+
+def test_mtl_loader_matches_the_reference_executed_fixture(oa, io_ref, tmp_path):
+    assert len(io_ref["mtl"]) >= 14 and sum(k.startswith("bundled:") for k in io_ref["mtl"]) == 7
+    for key, rec in io_ref["mtl"].items():
+        names, vals = _oracle_mtl(oa, rec["text"], tmp_path)
+        assert names == rec["names"], key
+        assert np.array_equal(_bits(vals).reshape(-1, 13), np.array(rec["values_bits"], np.uint32).reshape(-1, 13)), key
+
+
+def test_default_mtl_matches_the_reference_executed_fixture(oa, io_ref, tmp_path):
+    want = np.array(io_ref["default_mtl_bits"], np.uint32)
+    assert np.array_equal(want.view(np.float32), np.float32([.3, .3, .3, .5, .5, .5, 1, 1, 1, 10, 0, 1, 0]))    # mtl.hpp:21-39
+    m = oa.make_mtl()                                   # the Python-side default the tests build materials from
+    assert np.array_equal(_bits([*m.ka, *m.kd, *m.ks, m.ns, m.ni, m.d, float(m.illum)]), want)
+    _, vals = _oracle_mtl(oa, "", tmp_path)             # mtlIO.hpp:114-119: no material in the file -> one Mtl()
+    assert np.array_equal(_bits(vals[0]), want)
+
+
+def test_ppm_writer_matches_the_reference_executed_fixture(oa, io_ref, tmp_path):
+    assert [r["n"] for r in io_ref["ppm"]] == [1, 2, 5, 16, 33]
+    for rec in io_ref["ppm"]:
+        n = rec["n"]
+        rgb = np.array(rec["rgb_bits"], np.uint32).view(np.float32).reshape(n, n, 3)
+        p = str(tmp_path / "o.ppm")
+        assert oa.lib().ora_ppm_write(p.encode(), fp(rgb), n, n, 0) == 0
+        assert open(p, newline="").read() == rec["text"], n
+    assert any("-" in r["text"] for r in io_ref["ppm"])         # negative channels print as negative numbers there
+
+
+def test_io_restatements_match_the_live_reference_build(oa, tmp_path):
+    if oa.ref() is None or not hasattr(oa.ref(), "ref_load_mtl"):
+        pytest.skip("oracle/_ref/libref.so not built with the I/O doors (no /root/reference on this machine)")
+    rng = np.random.default_rng(99)
+    for n in (3, 24):
+        rgb = (rng.random((n, n, 3)) * 3 - 1).astype(np.float32)
+        oa.ref_write_ppm(tmp_path / "r.ppm", rgb)
+        assert oa.lib().ora_ppm_write(str(tmp_path / "o.ppm").encode(), fp(rgb), n, n, 0) == 0
+        assert open(tmp_path / "o.ppm", "rb").read() == open(tmp_path / "r.ppm", "rb").read()
+    keys = ["Ka", "Kd", "Ks", "Ns", "Ni", "d", "illum", "Tf", "#"]
+    for it in range(40):
+        lines = []
+        for _ in range(int(rng.integers(1, 12))):
+            k = keys[int(rng.integers(0, len(keys)))]
+            if rng.random() < 0.25:
+                lines.append("newmtl m%d" % len(lines))
+            nums = " ".join("%.6g" % x for x in rng.normal(0, 2, 3 if k in ("Ka", "Kd", "Ks", "Tf") else 1))
+            lines.append(k + (" " if rng.random() < 0.9 else "  ") + nums + (" " if rng.random() < 0.2 else ""))
+        text = "newmtl first\n" + "\n".join(lines) + "\n"
+        with open(tmp_path / "t.mtl", "w", newline="") as fh:
+            fh.write(text)
+        rnames, rvals = oa.ref_load_mtl(tmp_path / "t.mtl")
+        names, vals = _oracle_mtl(oa, text, tmp_path)
+        assert names == rnames, text
+        assert np.array_equal(_bits(vals), _bits(rvals)), text
