@@ -5,18 +5,21 @@ intersection path, one process per GPU.
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One step = one frame of the workload: every rank renders its image tiles
-(rtx_render_tiles_dev, scene replicated per GPU), then the colour image is gathered to rank 0
-(RCCL) and put back into row-major order.  value = rays traced by all ranks in the K timed frames / wall
-time (max over ranks).  Total work is fixed as N grows: "strong" scaling.
+One step = one frame of the workload, each frame from the next camera of a slow orbit around the scene (an
+animation, not one view rendered again and again): every rank renders its image tiles
+(rtx_render_tiles_batch_dev, scene replicated per GPU), then the frame is gathered to rank 0 (RCCL) as the
+3-byte pixels the reference writes to result.ppm (rtx_rgb_to_ppm8_dev; --out-format f32 for the float frame)
+and put back into row-major order.  The K timed steps (barrier + synchronise on both sides) are repeated
+--repeats times; value / ms_per_step are the MEDIAN repeat's (every repeat is listed), value = rays traced by all
+ranks in its K frames / wall time (max over ranks).  Total work is fixed as N grows: "strong" scaling.
 
 The JSON line also carries
-  roofline      for the dominant traversal kernel: algorithmic bytes (SURVEY 8(d):
-                32 B per node visited + 36 B per triangle tested + io per ray, counted by the
-                CPU mirror traversal of the same BVH on a strided sample of the same rays)
-                divided by that kernel's HIP-event duration, against 8 TB/s;
+  single_frame  one frame per call, one call at a time: the latency figure Flyscene::raytraceScene corresponds to;
+  verify        one batch re-rendered with RTX_FLAG_VERIFY: sampled rays re-checked by brute force over every triangle;
+  roofline      for the dominant traversal kernel: HBM-side traffic / its HIP-event duration against 8 TB/s, the
+                SURVEY 8(d) byte model beside it (survey_8d_frac: load demand, served by the caches), the VALU bound;
   cpu_baseline  the CPU oracle (brute-force reference path) timed on this host on a bounded
-                sample of the same rays.
+                sample of the same rays; roofline.cpu_bvh_full_frame = the same BVH walked by the host's cores.
 """
 import argparse
 import ctypes
@@ -41,7 +44,7 @@ def build_workload(name, api, scenes):
         verts, idx = scenes.soup(1000000, seed=0x5EED0001, h=0.02)
         m = mk(ka=(0, 0, 0), kd=(.7, .7, .7), ks=(.2, .2, .2), ns=10.0, ni=0.0, d=1.0, illum=2)
         return dict(verts=verts, idx=idx, tri_mat=np.zeros(len(idx), np.int32), mats=[m], lights=[[-2.0, 2.0, 2.0]],
-                    view=scenes.look_at_view((0, 0, 3), (0, 0, 0)), W=3840, H=2160, opts=(0, 1, 0, 0, 1, 1), spp=1)
+                    view=scenes.look_at_view((0, 0, 3), (0, 0, 0)), path=((0, 0, 3), (0, 0, 0)), W=3840, H=2160, opts=(0, 1, 0, 0, 1, 1), spp=1)
     if name == "soup5M_4k_16l_16spp":
         verts, idx = scenes.soup(5000000, seed=0x5EED0005, h=0.012)
         m = mk(ka=(0, 0, 0), kd=(.7, .7, .7), ks=(.2, .2, .2), ns=10.0, ni=0.0, d=1.0, illum=2)
@@ -58,19 +61,21 @@ def build_workload(name, api, scenes):
         m = mk()   # Tucano Mtl() defaults
         return dict(verts=verts, idx=idx, tri_mat=np.zeros(len(idx), np.int32), mats=[m],
                     lights=[list(c + r * np.array([-1.0, 1.0, 1.0]))],
-                    view=scenes.look_at_view(c + np.array([0, 0, 2 * r]), c), W=1920, H=1080, opts=(0, 1, 0, 0, 1, 1), spp=1)
+                    view=scenes.look_at_view(c + np.array([0, 0, 2 * r]), c), path=(c + np.array([0, 0, 2 * r]), c), W=1920, H=1080,
+                    opts=(0, 1, 0, 0, 1, 1), spp=1)
     if name == "hall262k_1080p_reflect3":
         verts, idx, tm = scenes.hall()
         wall = mk(ka=(.1, .1, .1), kd=(.6, .55, .5), ks=(.3, .3, .3), ns=20.0, ni=1.0, d=0.5, illum=2)
         col = mk(ka=(.1, .1, .1), kd=(.5, .6, .7), ks=(.6, .6, .6), ns=40.0, ni=1.0, d=0.5, illum=2)
         return dict(verts=verts, idx=idx, tri_mat=tm, mats=[wall, col], lights=[[0.0, 2.7, 0.0]],
-                    view=scenes.look_at_view((0.3, 1.6, 7.0), (0.0, 1.2, 0.0)), W=1920, H=1080, opts=(3, 1, 0, 0, 1, 1), spp=1)
+                    view=scenes.look_at_view((0.3, 1.6, 7.0), (0.0, 1.2, 0.0)), path=((0.3, 1.6, 7.0), (0.0, 1.2, 0.0), 0.02), W=1920, H=1080,
+                    opts=(3, 1, 0, 0, 1, 1), spp=1)
     if name == "planeobj_512_primary_shadow":
         z = np.load(os.path.join(ROOT, "tests", "golden", "scene_planeobj.npz"))
         mats = [mk(ka=tuple(m[0:3]), kd=tuple(m[3:6]), ks=tuple(m[6:9]), ns=float(m[9]), ni=float(m[10]), d=float(m[11]),
                    illum=int(m[12])) for m in z["mats"]]
         return dict(verts=z["verts"], idx=z["idx"], tri_mat=z["tri_mat"], mats=mats, lights=[[-1.0, 1.0, 1.0]],
-                    view=scenes.default_view(), W=512, H=512, opts=(0, 1, 0, 0, 1, 1), spp=1)
+                    view=scenes.default_view(), path=((0, 0, 2), (0, 0, 0)), W=512, H=512, opts=(0, 1, 0, 0, 1, 1), spp=1)
     raise SystemExit("unknown workload %s" % name)
 
 
@@ -122,22 +127,38 @@ def launch_ranks(args):
     raise SystemExit(rc)
 
 
+def frame_view(wl, scenes, k, static=False):
+    """View matrix of frame k of the run: the workload's camera on a slow orbit about the scene (0.25 degrees per
+    frame; the hall's camera, which stands inside, 0.02), or the one fixed view of SURVEY 8(d) with --static-camera."""
+    if static or "path" not in wl or k == 0:
+        return wl["view"]
+    eye, target = wl["path"][0], wl["path"][1]
+    return scenes.orbit_view(eye, target, k, wl["path"][2] if len(wl["path"]) > 2 else 0.25)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default=WORKLOADS[0], choices=WORKLOADS)
+    ap.add_argument("--repeats", type=int, default=5, help="the K timed steps are run this many times (each bracketed by barrier + synchronise); "
+                                                           "the median repeat is reported, all are listed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=6144, help="primary rays in the cpu_baseline sample")
     ap.add_argument("--roofline-stride", type=int, default=16, help="every k-th pixel feeds the byte count")
     ap.add_argument("--no-scaling-proxy", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-frame and verification passes")
+    ap.add_argument("--static-camera", action="store_true", help="every frame from the same camera (rounds 1-2 measured that)")
+    ap.add_argument("--out-format", default="rgb8", choices=["rgb8", "f32"],
+                    help="what the ranks of an N > 1 run hand to rank 0: the P3 bytes of result.ppm (3 B/pixel) or the float frame (12)")
     ap.add_argument("--inflight", type=int, default=None, choices=[1, 2, 3, 4],
                     help="render calls in flight (rtx_render_*_enqueue): they run side by side on the GPU, each on its own streams; "
                          "default 2 for batches of frames, 4 for the passes of a frame with several samples per pixel (measured)")
-    ap.add_argument("--batch", type=int, default=8,
-                    help="frames per render call (rtx_render_tiles_batch_dev_enqueue, 1-16): one set of launches traces them all")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="frames per render call (rtx_render_tiles_batch_dev_enqueue, 1-64): one set of launches traces them all; "
+                         "default 8 x ranks (a rank's share of 8 N frames is as many rays as 8 whole frames)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -179,29 +200,41 @@ def main():
     info = scene.info()
     opts = api.Options(*wl["opts"])
     offsets = spp_offsets(wl["spp"])
-    cams = [api.make_camera(wl["view"], W, H, subpixel=o) for o in offsets]
     rect = (0, 0, W, H)
     kmax = tiles.max_local_tiles(W, H, TILE, world)
     # one rank owns the whole frame: render it row-major in place, nothing to gather or reassemble
     npix_local = kmax * TILE * TILE if world > 1 else W * H
-    pipelined = len(cams) == 1
-    B = max(1, min(args.batch, api.MAX_BATCH)) if pipelined else 1
+    pipelined = len(offsets) == 1
     if args.inflight is None:
         args.inflight = 2 if pipelined else 4
-    # Three sets of output buffers: the render of frame k+1 (librtx's own stream) overlaps the gather
-    # and reassembly of frame k (torch's streams); a set is reused only after the torch work that
-    # read it has finished (event per set).
+    if args.batch is None:
+        args.batch = 8 * world
+    B = max(1, min(args.batch, api.MAX_BATCH)) if pipelined else 1
+    # at least `inflight` calls per timed repeat, so that calls do run side by side when K is small against the batch
+    B = max(1, min(B, (args.steps + args.inflight - 1) // args.inflight))
+    rgb8 = world > 1 and args.out_format == "rgb8"
+    out_bpp = 3 if rgb8 else 12
+
+    def cams_of(k):
+        """The cameras of frame k: one per sub-pixel sample."""
+        view = frame_view(wl, scenes, k, args.static_camera)
+        return [api.make_camera(view, W, H, subpixel=o) for o in offsets]
+
+    # Output buffers in sets: the render of call k+1 (librtx's own streams) overlaps the gather and reassembly of call k
+    # (torch's streams); a set is reused only after the torch work that read it has finished (event per set).
     NSETS = max(3, args.inflight + 2)
     sets = []
     for _ in range(NSETS):
         b = {"rgb": torch.zeros((B * npix_local, 3), dtype=torch.float32, device=dev),
              "face": torch.full((B * npix_local, 1), -1, dtype=torch.int32, device=dev),
              "free": torch.cuda.Event()}
-        b["acc"] = torch.zeros_like(b["rgb"]) if len(cams) > 1 else None
+        b["acc"] = torch.zeros_like(b["rgb"]) if not pipelined else None
+        if rgb8:
+            b["rgb8"] = torch.zeros((B * npix_local, 3), dtype=torch.uint8, device=dev)
         if world > 1 and rank == 0:
-            b["img"] = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
+            b["img"] = torch.empty((B, H, W, 3), dtype=torch.uint8 if rgb8 else torch.float32, device=dev)
         if world > 1 and rank == 0 and not rehearse:
-            b["g_rgb"] = torch.empty((world, B * npix_local, 3), dtype=torch.float32, device=dev)
+            b["g"] = torch.empty((world, B * npix_local, 3), dtype=torch.uint8 if rgb8 else torch.float32, device=dev)
         b["free"].record()
         sets.append(b)
     state = {"k": 0}
@@ -210,32 +243,36 @@ def main():
         """The finished local pixels of nf frames -> the last of those frames on rank 0 (None elsewhere)."""
         if world == 1:
             return (out.view(-1, H, W, 3)[nf - 1], face.view(-1, H, W, 1)[nf - 1])
-        # several ranks: the frames that travel are the colour images (what raytraceScene produces); hit ids
-        # stay where they were computed (12 instead of 16 bytes per pixel into rank 0 and through assemble).
+        # several ranks: what travels is the colour image (what raytraceScene produces) -- by default as the bytes the
+        # reference writes to result.ppm, quantised where the pixels lie; hit ids stay where they were computed.
         # One gather per render call: all nf frames of the batch at once.
         out = out[: nf * npix_local]
+        if rgb8:
+            api.rgb_to_ppm8_dev(out.data_ptr(), nf * npix_local, b["rgb8"].data_ptr(), torch.cuda.current_stream().cuda_stream)
+            out = b["rgb8"][: nf * npix_local]
         if rehearse:
-            g_rgb = tiles.gather_to_root(out.cpu(), world, rank, dist)
+            g = tiles.gather_to_root(out.cpu(), world, rank, dist)
             if rank == 0:
-                g_rgb = g_rgb.to(dev)
+                g = g.to(dev)
         else:
-            g_rgb = tiles.gather_to_root(out, world, rank, dist, b["g_rgb"][:, : nf * npix_local] if rank == 0 else None)
+            g = tiles.gather_to_root(out, world, rank, dist, b["g"][:, : nf * npix_local] if rank == 0 else None)
         if rank == 0:
-            # one pass per frame back to row-major (rtx_tiles_assemble_dev on torch's stream; tiles.assemble is its torch twin)
-            stride = g_rgb.stride(0) // 3
+            # one pass per frame back to row-major (rtx_tiles_assemble_*_dev on torch's stream; tiles.assemble is its torch twin)
+            stride = g.stride(0) // 3
             for f in range(nf):
-                api.tiles_assemble_dev(g_rgb.data_ptr() + f * npix_local * 12, world, stride, rect, TILE, 3, b["img"][f].data_ptr(),
-                                       torch.cuda.current_stream().cuda_stream)
+                api.tiles_assemble_bytes_dev(g.data_ptr() + f * npix_local * out_bpp, world, stride, rect, TILE, out_bpp, b["img"][f].data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream)
             return (b["img"][nf - 1], None)
         return None
 
-    spp_rgb = [torch.zeros((npix_local, 3), dtype=torch.float32, device=dev) for _ in cams] if len(cams) > 1 else None
+    spp_rgb = [torch.zeros((npix_local, 3), dtype=torch.float32, device=dev) for _ in offsets] if not pipelined else None
 
-    def frame():
-        """One frame of several samples per pixel: the passes (one camera per sub-pixel offset) are enqueued side by side,
-        each into a buffer of its own, then summed in pass order and averaged; gather to rank 0, assemble."""
+    def frame(kf):
+        """Frame kf of the path at several samples per pixel: the passes (one camera per sub-pixel offset) are enqueued side by
+        side, each into a buffer of its own, then summed in pass order and averaged; gather to rank 0, assemble."""
         b = sets[state["k"] % NSETS]
         state["k"] += 1
+        cams = cams_of(kf)
         face, acc = b["face"], b["acc"]
         rays = [0, 0, 0]
         ms = [0.0, 0.0, 0.0]
@@ -270,19 +307,20 @@ def main():
         b["free"].record()
         return rays, ms, img
 
-    # Frames of a sequence go to the library B at a time (one camera per frame -- the same one here, the library
-    # does not know that): one set of launches traces and shades the rank's tiles of all B frames.
+    # Frames of a sequence go to the library B at a time, one camera per frame: one set of launches traces and shades
+    # the rank's tiles of all B frames.
     host = {"wait_buffers": 0.0, "enqueue": 0.0, "wait_render": 0.0, "exchange": 0.0}    # where rank 0's host time goes (seconds)
 
-    def batch_enqueue(nf):
+    def batch_enqueue(k0, nf):
         b = sets[state["k"] % NSETS]
         state["k"] += 1
+        cams = [cams_of(k0 + f)[0] for f in range(nf)]
         t_a = time.perf_counter()
         b["free"].synchronize()
         t_b = time.perf_counter()
         host["wait_buffers"] += t_b - t_a
         b["nf"] = nf
-        scene.render_tiles_batch_dev([cams[0]] * nf, opts, rect, TILE if world > 1 else 0, rank if world > 1 else 0, world,
+        scene.render_tiles_batch_dev(cams, opts, rect, TILE if world > 1 else 0, rank if world > 1 else 0, world,
                                      b["rgb"].data_ptr(), None, b["face"].data_ptr(), enqueue=True)
         host["enqueue"] += time.perf_counter() - t_b
         return b
@@ -299,18 +337,18 @@ def main():
         host["exchange"] += time.perf_counter() - t_b
         return rays, ms, img
 
-    def frames(n):
-        """n frames; returns (rays, ms, img) per render call (per frame, or per batch of up to B frames)."""
+    def frames(n, k0=0):
+        """Frames k0 .. k0 + n - 1 of the camera path; returns (rays, ms, img) per render call (per frame, or per batch of up to B frames)."""
         out = []
         if not pipelined:
-            return [frame() for _ in range(n)]
+            return [frame(k0 + i) for i in range(n)]
         flying = []
         left = n
         ncalls = (n + B - 1) // B                # calls of (nearly) equal size: 20 frames at B = 8 go as 7 + 7 + 6
         while left > 0:
             nf = (left + ncalls - 1) // ncalls
             ncalls -= 1
-            flying.append(batch_enqueue(nf))
+            flying.append(batch_enqueue(k0 + n - left, nf))
             left -= nf
             if len(flying) >= args.inflight:
                 out.append(batch_finish(flying.pop(0)))
@@ -326,68 +364,125 @@ def main():
 
     # setup, not steps: the library times its wave schedulers on its first seven render calls of a
     # scene and keeps the fastest per launch kind; let that settle before the warmup / timed steps
+    # Every timed repeat renders the SAME K frames of the path (frames 0 .. K-1; frame 0 is SURVEY 8(d)'s camera), so that the
+    # repeats differ by noise only; within a repeat every frame has its own camera.
     frames(7 * B)
-    frames(args.warmup)
-    sync()
-    for k in host:
-        host[k] = 0.0
-    t0 = time.perf_counter()
-    rays_tot = np.zeros(3, np.int64)
-    ms_tot = np.zeros(3, np.float64)
+    frames(args.warmup, max(0, args.steps - args.warmup))
+    R = max(1, args.repeats)
+    rep_dt, rep_rays, rep_ms, rep_host = [], [], [], []
     img = None
-    for r, m, img in frames(args.steps):
-        rays_tot += r
-        ms_tot += m
-    t_loop = time.perf_counter() - t0
-    sync()
-    dt = time.perf_counter() - t0
-    host_ms = {k: v / args.steps * 1e3 for k, v in host.items()}
-    host_ms["final_sync"] = (dt - t_loop) / args.steps * 1e3
-    # whole-job aggregates: rays summed over ranks, time = max over ranks
-    agg = torch.tensor([float(rays_tot[0]), float(rays_tot[1]), float(rays_tot[2])], dtype=torch.float64, device="cpu" if rehearse else dev)
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
+    for _ in range(R):
+        sync()
+        for k in host:
+            host[k] = 0.0
+        t0 = time.perf_counter()
+        rays_tot = np.zeros(3, np.int64)
+        ms_tot = np.zeros(3, np.float64)
+        for r, m, img in frames(args.steps):
+            rays_tot += r
+            ms_tot += m
+        t_loop = time.perf_counter() - t0
+        sync()
+        dt = time.perf_counter() - t0
+        hm = {k: v / args.steps * 1e3 for k, v in host.items()}
+        hm["final_sync"] = (dt - t_loop) / args.steps * 1e3
+        rep_dt.append(dt); rep_rays.append(rays_tot); rep_ms.append(ms_tot); rep_host.append(hm)
+    # whole-job aggregates per repeat: rays summed over ranks, time = max over ranks
+    cdev = "cpu" if rehearse else dev
+    agg = torch.tensor(np.asarray(rep_rays, np.float64), dtype=torch.float64, device=cdev)          # [R, 3]
+    tmax = torch.tensor(rep_dt, dtype=torch.float64, device=cdev)
     if dist is not None:
         dist.all_reduce(agg)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    total_rays = float(agg.sum().item())
-    dt = float(tmax.item())
+    agg = agg.cpu().numpy()
+    tmax = tmax.cpu().numpy()
+    values = [float(agg[i].sum() / tmax[i] / 1e6) for i in range(R)]
+    med = int(np.argsort(values)[(R - 1) // 2])    # the repeat with the median rate (the lower one of an even count): frames of a camera path differ in rays
+    dt = float(tmax[med])
+    total_rays = float(agg[med].sum())
+    rays_tot, ms_tot, host_ms = rep_rays[med], rep_ms[med], rep_host[med]
+
     # Per-kernel durations for the roofline: frames in flight share the GPU, so the HIP-event spans of the timed
-    # region include time given to the other frames' kernels.  The same frames once more, one at a time
-    # (synchronous calls, nothing beside them): these spans are each kernel's own duration.
-    # (the same launches as in the timed region: B frames per call)
+    # region include time given to the other frames' kernels.  The same kind of calls once more, one at a time
+    # (synchronous, nothing beside them): these spans are each kernel's own duration.
     ms_iso = None
+    iso_views = []
+    single = None
+    verify = None
     if world == 1:
         ms_iso = np.zeros(3, np.float64)
         ncalls = max(2, args.steps // B)
-        for _ in range(ncalls):
-            for cam in cams:
-                scene.render_tiles_batch_dev([cam] * B, opts, rect, 0, 0, 1, sets[0]["rgb"].data_ptr(), None, sets[0]["face"].data_ptr())
+        for c in range(ncalls):
+            k0 = (c * B) % max(1, args.steps)
+            for si in range(len(offsets)):
+                cams = [cams_of(k0 + f)[si] for f in range(B)]
+                scene.render_tiles_batch_dev(cams, opts, rect, 0, 0, 1, sets[0]["rgb"].data_ptr(), None, sets[0]["face"].data_ptr())
                 st = scene.stats()
                 ms_iso += [st.ms_trace_camera, st.ms_trace - st.ms_trace_camera, st.ms_total]
+            if c == 0:
+                iso_views = [frame_view(wl, scenes, k0 + f, args.static_camera) for f in range(B)]
         ms_iso /= ncalls * B
+    if world == 1 and pipelined and not args.no_extras:
+        # One frame per call, one call at a time: what Flyscene::raytraceScene (src/flyscene.cpp:395-439) corresponds to.
+        def one(n):
+            rays = 0
+            for kf in range(n):
+                scene.render_tiles_batch_dev(cams_of(kf), opts, rect, 0, 0, 1, sets[0]["rgb"].data_ptr(), None, sets[0]["face"].data_ptr())
+                st = scene.stats()
+                rays += st.rays_primary + st.rays_shadow + st.rays_reflection
+            return rays
+        one(10)                                   # the tuner's trials for this size class
+        times = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            rays1 = one(max(8, min(args.steps, 32)))
+            torch.cuda.synchronize()
+            times.append(((time.perf_counter() - t1) / max(8, min(args.steps, 32)), rays1 / max(8, min(args.steps, 32))))
+        times.sort()
+        single = {"ms_per_frame": times[1][0] * 1e3, "mrays_per_s": times[1][1] / times[1][0] / 1e6, "ms_per_frame_min": times[0][0] * 1e3,
+                  "note": "one frame per render call, one call at a time (host wait included): the latency of a single raytraceScene"}
+        # The timed configuration once more with the standing check on: every camera launch re-checks ~2,000 of its rays by
+        # brute force over every triangle (the reference's own algorithm); a mismatch would be a hit the hierarchy lost.
+        scene.set_flags(api.FLAG_VERIFY)
+        cams = [cams_of(f)[0] for f in range(B)]
+        scene.render_tiles_batch_dev(cams, opts, rect, 0, 0, 1, sets[0]["rgb"].data_ptr(), None, sets[0]["face"].data_ptr())
+        st = scene.stats()
+        scene.set_flags(0)
+        verify = {"checked": int(st.verify_checked), "mismatches": int(st.verify_mismatches), "rays_out_of_domain": int(st.rays_out_of_domain),
+                  "note": "RTX_FLAG_VERIFY on one batch of %d frames: sampled camera rays re-traced by brute force over all triangles" % B}
     # pixels whose primary ray hit geometry, from the hit ids of the last frame on every rank
-    last = sets[(state["k"] - 1) % NSETS]["face"][:npix_local]
-    nhit = torch.tensor([float((last >= 0).sum().item())], dtype=torch.float64, device="cpu" if rehearse else dev)
+    lb = sets[(state["k"] - 1) % NSETS]
+    nf_last = lb.get("nf", 1) if pipelined and world > 1 else 1          # (a lone rank's later passes reuse set 0 for whole batches: frame 0)
+    last = lb["face"][(nf_last - 1) * npix_local: nf_last * npix_local]
+    nhit = torch.tensor([float((last >= 0).sum().item())], dtype=torch.float64, device=cdev)
     if dist is not None:
         dist.all_reduce(nhit)
 
     result = None
     if rank == 0:
         hits = int(nhit.item())
+        gather_bytes = 0 if world == 1 else int((world - 1) * npix_local * out_bpp)
         result = {
             "metric": "Mrays/sec (primary+shadow+reflection)", "value": total_rays / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "repeats": {"n": R, "reported": "median", "value": sorted(values), "ms_per_step": sorted(float(x) / args.steps * 1e3 for x in tmax),
+                        "spread": (max(values) - min(values)) / float(np.median(values)) if R > 1 else 0.0},
             "config": {"workload": args.workload, "triangles": int(info.ntris), "bvh_nodes": int(info.nnodes),
                        "bvh_build_ms_host": float(info.build_ms), "scene_device_bytes": int(info.device_bytes),
                        "triangles_outside_bvh": int(info.nwild),
                        "image": [W, H], "lights": len(wl["lights"]), "spp": wl["spp"], "max_bounces": wl["opts"][0],
-                       "tile": TILE, "partition": (("image tiles round-robin over %d ranks, scene replicated, RGB gathered to rank 0" % world) if world > 1
+                       "camera": "one fixed view" if args.static_camera else "a camera path: every frame from the next position of an orbit about the scene (%.2f degrees per frame)"
+                                 % (wl["path"][2] if len(wl.get("path", ())) > 2 else 0.25),
+                       "tile": TILE, "partition": (("image tiles round-robin over %d ranks, scene replicated, %s gathered to rank 0" % (world, "P3 bytes (rtx_rgb_to_ppm8_dev)" if rgb8 else "float RGB")) if world > 1
                                      else "one rank renders the whole frame row-major") + (("; %d frames per render call (rtx_render_tiles_batch_dev_enqueue), %d calls in flight" % (B, args.inflight)) if pipelined
-                                        else "; %d passes per frame (one per sub-pixel sample), %d in flight, summed in pass order" % (len(cams), args.inflight)),
+                                        else "; %d passes per frame (one per sub-pixel sample), %d in flight, summed in pass order" % (len(offsets), args.inflight)),
                        "frames_per_call": B, "calls_in_flight": args.inflight,
-                       "rays_per_frame": {"primary": int(agg[0].item() / args.steps), "shadow": int(agg[1].item() / args.steps),
-                                          "reflection": int(agg[2].item() / args.steps)},
+                       "gather": {"format": ("rgb8" if rgb8 else "f32") if world > 1 else None, "bytes_per_pixel": out_bpp if world > 1 else None,
+                                  "bytes_into_rank0_per_frame": gather_bytes},
+                       "rays_per_frame": {"primary": int(agg[med][0] / args.steps), "shadow": int(agg[med][1] / args.steps),
+                                          "reflection": int(agg[med][2] / args.steps)},
                        "pixels_hitting_geometry": hits,
                        # rank 0's host thread, ms per frame of the timed region: waiting for a free buffer set (torch still gathering /
                        # reassembling an earlier call), enqueueing, waiting for the render, issuing gather + reassembly, the last sync
@@ -397,19 +492,29 @@ def main():
                                                            "trace_queue": ms_tot[1] / args.steps,
                                                            "all_kernels": ms_tot[2] / args.steps}},
         }
+        if single is not None:
+            result["single_frame"] = single
+        if verify is not None:
+            result["verify"] = verify
     if rank == 0 and rehearse:
         result["config"]["rehearsal"] = True
-        if len(cams) == 1:      # the reassembled parts against one full-frame render, bit for bit
+        if pipelined:      # the reassembled parts against one full-frame render of the same camera, bit for bit
             f_rgb = torch.zeros((W * H, 3), dtype=torch.float32, device=dev)
             f_face = torch.full((W * H, 1), -1, dtype=torch.int32, device=dev)
-            scene.render_dev(cams[0], opts, rect, f_rgb.data_ptr(), None, f_face.data_ptr())
-            result["config"]["rehearsal_equals_full_frame"] = bool(
-                hits == int((f_face >= 0).sum().item()) and torch.equal(img[0].reshape(-1, 3).view(torch.int32), f_rgb.view(torch.int32)))
-    if rank == 0 and world == 1 and not args.no_scaling_proxy:
-        result["scaling_proxy"] = scaling_proxy(scene, cams[0], opts, rect, W, H, torch, dev, tiles, max(5, args.steps), args.inflight, B)
+            scene.render_dev(cams_of(args.steps - 1)[0], opts, rect, f_rgb.data_ptr(), None, f_face.data_ptr())
+            want = f_rgb
+            if rgb8:
+                want = torch.zeros((W * H, 3), dtype=torch.uint8, device=dev)
+                api.rgb_to_ppm8_dev(f_rgb.data_ptr(), W * H, want.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            got = img[0].reshape(-1, 3)
+            same = torch.equal(got, want) if rgb8 else torch.equal(got.view(torch.int32), want.view(torch.int32))
+            result["config"]["rehearsal_equals_full_frame"] = bool(hits == int((f_face >= 0).sum().item()) and same)
+    if rank == 0 and world == 1 and not args.no_scaling_proxy and pipelined:
+        result["scaling_proxy"] = scaling_proxy(scene, lambda k: cams_of(k)[0], opts, rect, W, H, torch, dev, tiles, args.inflight)
     if rank == 0 and world == 1 and not args.no_roofline:
         result["config"]["kernel_ms_per_frame_one_call_at_a_time"] = {"trace_camera": ms_iso[0], "trace_queue": ms_iso[1], "all_kernels": ms_iso[2]}
-        result["roofline"] = roofline(args, wl, scene, info, ms_iso, rays_tot / args.steps, B)
+        result["roofline"] = roofline(args, wl, scene, info, ms_iso, rays_tot / args.steps, B, iso_views)
         ent = result["roofline"]["rays_entering_bvh_per_frame"]
         # rays that pass the reference's root-box gate and walk the hierarchy (the rest end at the gate: the camera of
         # SURVEY 8(d) sees past the soup on more than half of the frame)
@@ -425,41 +530,66 @@ def main():
     scene.close()
 
 
-def scaling_proxy(scene, cam, opts, rect, W, H, torch, dev, tiles, steps, inflight=2, batch=1):
-    """Strong scaling rehearsed on one GPU: the share of rank 0 of N (rtx_render_tiles_dev, part 0 of N, the
-    call every rank of an N-GPU run makes) timed alone, in batches and with calls in flight like the bench loop.  With perfect
-    scaling part 0 of N costs 1/N of part 0 of 1; the ratio is the render-side bound on the N-GPU speed-up
-    (the RGB gather and reassembly on rank 0 come on top and overlap the next frame's render)."""
-    ms = {}
+def scaling_proxy(scene, cam_of, opts, rect, W, H, torch, dev, tiles, inflight=2):
+    """Strong scaling rehearsed on one GPU: the share of rank 0 of N (rtx_render_tiles_batch_dev, part 0 of N, the
+    call every rank of an N-GPU run makes) timed alone, the way the bench loop of an N-rank run issues it: 8 N frames
+    per call (a share of 8 N frames holds as many rays as 8 whole frames), `inflight` calls in flight, every frame from
+    the next camera of the path.  With perfect scaling part 0 of N costs 1/N of part 0 of 1; the ratio is the render-side
+    bound on the N-GPU speed-up (the gather and reassembly on rank 0 come on top and overlap the next call's render).
+    Each N is timed three times over >= 128 frames (the spans are short: one repeat of 20 frames of a 1/8 share is 4 ms
+    and its timing moved by 15 % from run to run); min and median are printed."""
+    from raytracing_project_amd import api
+    ms, ms_med, spans, batch_of, gather = {}, {}, {}, {}, {}
+    k0 = 100000                                   # (camera indices of their own: these frames belong to no timed step)
     for nparts in (1, 2, 4, 8):
+        batch = min(api.MAX_BATCH, 8 * nparts)
         kmax = tiles.max_local_tiles(W, H, TILE, nparts)
-        rgb = torch.zeros((batch * kmax * TILE * TILE, 3), dtype=torch.float32, device=dev)
-        face = torch.full((batch * kmax * TILE * TILE, 1), -1, dtype=torch.int32, device=dev)
+        npl = kmax * TILE * TILE if nparts > 1 else W * H
+        rgb = torch.zeros((batch * npl, 3), dtype=torch.float32, device=dev)
+        face = torch.full((batch * npl, 1), -1, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
+        acc = {"cam": 0.0, "queue": 0.0, "all": 0.0, "frames": 0}
 
-        def run(n):
-            flying = 0
+        def run(n, k):
+            flying = []
             left = n
             while left > 0:
                 nf = min(batch, left)
                 left -= nf
-                scene.render_tiles_batch_dev([cam] * nf, opts, rect, TILE, 0, nparts, rgb.data_ptr(), None, face.data_ptr(), enqueue=True)
-                flying += 1
-                if flying >= inflight:
-                    scene.render_finish()
-                    flying -= 1
-            for _ in range(flying):
-                scene.render_finish()
-        run(8 * batch)                           # the scheduler tuner starts over when the ray count changes 2x
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run(steps)
-        torch.cuda.synchronize()
-        ms[nparts] = (time.perf_counter() - t0) / steps * 1e3
-    return {"ms_per_frame_part0_of_N": {str(n): ms[n] for n in ms},
-            "render_speedup_bound": {str(n): ms[1] / ms[n] for n in ms},
-            "note": "one GPU renders rank 0's tiles of an N-rank run (same tile size, same round-robin); "
-                    "ms[1] / ms[N] bounds the N-GPU speed-up from the render side"}
+                cams = [cam_of(k + f) for f in range(nf)]
+                k += nf
+                scene.render_tiles_batch_dev(cams, opts, rect, TILE if nparts > 1 else 0, 0, nparts, rgb.data_ptr(), None, face.data_ptr(), enqueue=True)
+                flying.append(nf)
+                if len(flying) >= inflight:
+                    st = scene.render_finish(); nfd = flying.pop(0)
+                    acc["cam"] += st.ms_trace_camera; acc["queue"] += st.ms_trace - st.ms_trace_camera; acc["all"] += st.ms_total; acc["frames"] += nfd
+            while flying:
+                st = scene.render_finish(); nfd = flying.pop(0)
+                acc["cam"] += st.ms_trace_camera; acc["queue"] += st.ms_trace - st.ms_trace_camera; acc["all"] += st.ms_total; acc["frames"] += nfd
+        run(8 * batch, k0)                        # the scheduler tuner's trials for this size class
+        n = max(128, 2 * inflight * batch)
+        n = (n + batch - 1) // batch * batch
+        t = []
+        for rep in range(3):
+            torch.cuda.synchronize()
+            acc.update(cam=0.0, queue=0.0, all=0.0, frames=0)
+            t0 = time.perf_counter()
+            run(n, k0 + 1000 * (rep + 1))
+            torch.cuda.synchronize()
+            t.append((time.perf_counter() - t0) / n * 1e3)
+        t.sort()
+        ms[nparts], ms_med[nparts] = t[0], t[1]
+        spans[nparts] = {"trace_camera": acc["cam"] / acc["frames"], "trace_queue": acc["queue"] / acc["frames"], "all_kernels": acc["all"] / acc["frames"]}
+        batch_of[nparts] = batch
+        gather[nparts] = {"rgb8": int((nparts - 1) * npl * 3) if nparts > 1 else 0, "f32": int((nparts - 1) * npl * 12) if nparts > 1 else 0}
+        del rgb, face
+    return {"ms_per_frame_part0_of_N": {str(n): ms_med[n] for n in ms}, "ms_per_frame_part0_of_N_min": {str(n): ms[n] for n in ms},
+            "render_speedup_bound": {str(n): ms_med[1] / ms_med[n] for n in ms}, "render_speedup_bound_of_min": {str(n): ms[1] / ms[n] for n in ms},
+            "frames_per_call": {str(n): batch_of[n] for n in ms}, "calls_in_flight": inflight,
+            "kernel_span_ms_per_frame_part0_of_N": {str(n): spans[n] for n in ms},
+            "gather_bytes_into_rank0_per_frame": {str(n): gather[n] for n in ms},
+            "note": "one GPU renders rank 0's tiles of an N-rank run (same tile size, same round-robin, 8 N frames per call, camera path); "
+                    "median (and min) of three timings of >= 128 frames; ms[1] / ms[N] bounds the N-GPU speed-up from the render side"}
 
 
 def oracle_scene(wl):
@@ -470,7 +600,7 @@ def oracle_scene(wl):
     return oa, s
 
 
-PMC_FILE = os.path.join("profiles", "r02_pmc.json")     # scripts/prof_derive.py --pmc-json over this round's rocprofv3 passes
+PMC_FILES = [os.path.join("profiles", "r03_pmc.json"), os.path.join("profiles", "r02_pmc.json")]   # scripts/prof_derive.py --pmc-json over a round's rocprofv3 passes (newest first)
 
 
 def any_blocker_shadows(wl):
@@ -484,68 +614,78 @@ def any_blocker_shadows(wl):
     return all(key(x) == key(m[0]) for x in m) and bool((tm >= 0).all() and (tm < len(m)).all())
 
 
-def roofline(args, wl, scene, info, ms, rays, frames_per_launch=1):
+def shadow_rays_of(wl, o, d1, t, hit):
+    """Hit points / shadow directions of the first light in numpy fp32 (ulp-level differences from the kernel's own values
+    do not move the visit counts): (P, dir, tmax)."""
+    dd = d1[hit]
+    d2 = dd / np.sqrt((dd * dd).sum(1, dtype=np.float32))[:, None]
+    P = (o[hit] + t[hit, None] * d2).astype(np.float32)
+    L = np.float32(wl["lights"][0])
+    sd = (L[None] - P).astype(np.float32)
+    dist = np.sqrt((sd * sd).sum(1, dtype=np.float32)).astype(np.float32)
+    return P, (sd / dist[:, None]).astype(np.float32), (dist * np.float32(1.001)).astype(np.float32)     # shadow_tmax(), rtx_kernels.h
+
+
+def roofline(args, wl, scene, info, ms, rays, frames_per_launch=1, views=None):
     """The dominant traversal kernel against the rooflines that could bound it.
 
     ms: per-frame kernel durations measured one render call at a time (HIP events on the library's stream); a call's
-    launches carry frames_per_launch frames (rtx_render_tiles_batch_dev), and every per-launch figure below is for
-    such a launch.
+    launches carry frames_per_launch frames (rtx_render_tiles_batch_dev, cameras `views`), and every per-launch figure
+    below is for such a launch.
     * algorithmic_bytes_per_launch: SURVEY 8(d)'s figure, 32 B per node visited + 36 B per triangle tested + io,
       counted by the CPU mirror (oracle/rt_oracle_bvh.c) walking the same BVH in the same order on every k-th
-      pixel's rays (shadow rays bounded at the light and stopped at any blocker exactly where the kernel does).
-      It is LOAD DEMAND: nearly all of it is served by L1 / L2 / Infinity Cache, so demand / duration may exceed
-      the HBM peak and is reported as `load_demand`, not as a fraction of HBM.
+      pixel's rays of those cameras (shadow rays bounded at the light and stopped at any blocker exactly where the
+      kernel does).  It is LOAD DEMAND: nearly all of it is served by L1 / L2 / Infinity Cache, so demand / duration
+      exceeds the HBM peak; it is printed as survey_8d_frac (the task's definition, non-physical above 1) and as
+      `load_demand` against the L2, never as the HBM figure.
     * achieved / frac (bound "hbm"): the bytes that did cross the HBM-side interface per launch (`traffic`, PMC
-      FETCH_SIZE x2 + WRITE_SIZE from this round's rocprofv3 passes of this command) / the launch duration
-      measured here, against 8 TB/s; without a PMC record, the compulsory bytes (scene + io touched once).
+      FETCH_SIZE x2 + WRITE_SIZE from the committed rocprofv3 passes of this command: traffic_source says which file;
+      counters cannot be read inside this run) / the launch duration measured here, against 8 TB/s; without a PMC
+      record, the compulsory bytes (scene + io touched once).
     * valu: the bound that binds -- VALU-busy share of the kernel's SIMD cycles x active lanes per VALU
       instruction (same PMC passes): the fraction of the vector ALU's lane-cycles doing useful work.
     """
     oa, osc = oracle_scene(wl)
     W, H = wl["W"], wl["H"]
     stride = max(1, args.roofline_stride)
+    B = frames_per_launch
+    views = list(views) if views else [wl["view"]]
     nodes, order = scene.bvh()
     tris = scene.tris()
     lo, hi = osc.root_box()
-    ocam = oa.make_camera(wl["view"], W, H)
-    o, d1 = oa.camera_rays(ocam, (0, 0, W, H))
-    pick = np.arange(0, W * H, stride)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = min(16, cores)
-    t_cpu0 = time.perf_counter()
-    t, f, nv, tt, gs, tf = oa.bvh_trace(nodes, tris, order, lo, hi, o[pick], d1[pick], threads=threads, nwild=info.nwild,
-                                        layout_counts=True)
-    cpu_bvh_s = time.perf_counter() - t_cpu0
-    prim_bytes = (32.0 * nv.sum() + 36.0 * tt.sum()) * stride + 8.0 * W * H
+    # the sample: every (stride * len(views))-th pixel of each camera of the launch, offsets staggered
+    o_l, d_l = [], []
+    for f, view in enumerate(views):
+        ocam = oa.make_camera(view, W, H)
+        o, d1 = oa.camera_rays(ocam, (0, 0, W, H))
+        pick = np.arange((f * stride) % (stride * len(views)), W * H, stride * len(views))
+        o_l.append(o[pick]); d_l.append(d1[pick])
+    o_s, d_s = np.concatenate(o_l), np.concatenate(d_l)
+    scale = float(W * H) / len(o_s)              # one frame's rays per sampled ray
+    t, f, nv, tt, gs, tf = oa.bvh_trace(nodes, tris, order, lo, hi, o_s, d_s, threads=threads, nwild=info.nwild, layout_counts=True)
+    prim_bytes = (32.0 * nv.sum() + 36.0 * tt.sum()) * scale + 8.0 * W * H
     # what the device layout really loads: 64-B packed groups, 16 B for a triangle's plane stage, 48 B more when it
     # goes on to the barycentrics, 8 B result
-    prim_layout = (64.0 * gs.sum() + 16.0 * tt.sum() + 48.0 * tf.sum()) * stride + 8.0 * W * H
-    entering = {"primary": int((gs > 0).sum()) * stride, "shadow": 0}
+    prim_layout = (64.0 * gs.sum() + 16.0 * tt.sum() + 48.0 * tf.sum()) * scale + 8.0 * W * H
+    entering = {"primary": int((gs > 0).sum() * scale), "shadow": 0}
     per_ray = {"primary_nodes": float(nv.mean()), "primary_tris": float(tt.mean()),
                "primary_nodes_of_rays_entering_bvh": float(nv[gs > 0].mean()) if (gs > 0).any() else 0.0}
     hit = f >= 0
     sh_bytes = sh_layout = 0.0
     anyhit = any_blocker_shadows(wl)
     if hit.any() and wl["opts"][4]:
-        # hit points / shadow directions in numpy fp32: ulp-level differences from the kernel's own values do not
-        # move the visit counts.  First light only, scaled by the light count.
-        dd = d1[pick][hit]
-        d2 = dd / np.sqrt((dd * dd).sum(1, dtype=np.float32))[:, None]
-        P = (o[pick][hit] + t[hit, None] * d2).astype(np.float32)
-        L = np.float32(wl["lights"][0])
-        sd = (L[None] - P).astype(np.float32)
-        dist = np.sqrt((sd * sd).sum(1, dtype=np.float32)).astype(np.float32)
-        sd1 = (sd / dist[:, None]).astype(np.float32)
-        tmax = (dist * np.float32(1.001)).astype(np.float32)             # shadow_tmax(), rtx_kernels.h
+        # first light only, scaled by the light count
+        P, sd1, tmax = shadow_rays_of(wl, o_s, d_s, t, hit)
         _, _, nv2, tt2, gs2, tf2 = oa.bvh_trace_shadow(nodes, tris, order, lo, hi, P, sd1, tmax, anyhit, threads=threads, nwild=info.nwild)
         nl = len(wl["lights"])
-        sh_bytes = ((32.0 * nv2.sum() + 36.0 * tt2.sum()) + 72.0 * len(P)) * stride * nl
-        sh_layout = ((64.0 * gs2.sum() + 16.0 * tt2.sum() + 48.0 * tf2.sum()) + 72.0 * len(P)) * stride * nl
-        entering["shadow"] = int((gs2 > 0).sum()) * stride * nl
+        sh_bytes = ((32.0 * nv2.sum() + 36.0 * tt2.sum()) + 72.0 * len(P)) * scale * nl
+        sh_layout = ((64.0 * gs2.sum() + 16.0 * tt2.sum() + 48.0 * tf2.sum()) + 72.0 * len(P)) * scale * nl
+        entering["shadow"] = int((gs2 > 0).sum() * scale) * nl
         per_ray.update({"shadow_nodes": float(nv2.mean()), "shadow_tris": float(tt2.mean()),
                         "shadow_rays_stop_at_any_blocker": bool(anyhit)})
     spp = wl["spp"]
-    B = frames_per_launch
     cand = [("k_trace_camera", prim_bytes * B, prim_layout * B, ms[0] / spp * B), ("k_trace_queue", sh_bytes * B, sh_layout * B, ms[1] / spp * B)]
     if wl["opts"][0] > 0:     # reflection launches share k_trace_queue's time; only the camera kernel is attributable
         cand = cand[:1]
@@ -553,26 +693,39 @@ def roofline(args, wl, scene, info, ms, rays, frames_per_launch=1):
     scene_bytes = 64.0 * (info.nnodes / 4.0) + 64.0 * info.ntris + 4.0 * info.ntris
     io_bytes = (8.0 * W * H if name == "k_trace_camera" else 40.0 * rays[1] / spp) * B
     compulsory = scene_bytes + io_bytes
-    pmc = {}
-    try:
-        with open(os.path.join(ROOT, PMC_FILE)) as fh:
-            pmc = json.load(fh).get(args.workload, {}).get(name, {})
-    except (OSError, ValueError):
-        pass
+    pmc, pmc_file = {}, None
+    for cand_file in PMC_FILES:
+        try:
+            with open(os.path.join(ROOT, cand_file)) as fh:
+                rec = json.load(fh).get(args.workload, {}).get(name, {})
+        except (OSError, ValueError):
+            continue
+        if rec:
+            pmc, pmc_file = rec, cand_file
+            break
     traffic = pmc.get("hbm_bytes_per_launch")
+    if traffic is not None and pmc.get("frames_per_launch", B) != B:      # the record is for launches of another size
+        traffic = traffic * B / pmc["frames_per_launch"]
     sec = kms * 1e-3
     hbm_bytes = traffic if traffic is not None else compulsory
     res = {"bound": "hbm", "kernel": name, "unit": "GB/s", "peak": HBM_PEAK_GBS,
            "achieved": hbm_bytes / sec / 1e9 if sec > 0 else 0.0,
            "traffic": traffic, "avg_launch_ms": kms, "frames_per_launch": B,
-           "achieved_is": ("HBM-side bytes per launch (traffic: PMC FETCH_SIZE x2 + WRITE_SIZE, %s) / the launch duration measured in this run"
-                           % PMC_FILE) if traffic is not None else "compulsory bytes per launch (no PMC record for this workload) / measured launch duration",
+           "traffic_source": ("committed: %s (rocprofv3 --pmc passes of this command in an earlier run; a PMC counter cannot be read inside the timed run)" % pmc_file)
+                             if traffic is not None else None,
+           "achieved_is": ("HBM-side bytes per launch (traffic: PMC FETCH_SIZE x2 + WRITE_SIZE, %s; FETCH_SIZE counts Infinity-Cache hits too, so this is L2-miss "
+                           "traffic, an upper bound on HBM bytes) / the launch duration measured in this run" % pmc_file) if traffic is not None
+                          else "compulsory bytes per launch (no PMC record for this workload) / measured launch duration",
            "compulsory_bytes_per_launch": compulsory,
            "algorithmic_bytes_per_launch": nbytes,
            "bytes_model": "SURVEY 8(d): 32 B/node visited + 36 B/triangle tested + io (8 B/primary, 72 B/queued ray); counts from the CPU "
-                          "mirror traversal of the same BVH on every %d-th pixel's rays, scaled" % stride,
+                          "mirror traversal of the same BVH on every %d-th pixel's rays of the launch's %d cameras, scaled" % (stride, len(views)),
            "per_ray": per_ray}
     res["frac"] = res["achieved"] / HBM_PEAK_GBS
+    # SURVEY 8(d)'s own figure: algorithmic bytes / launch duration / HBM peak.  Above 1 it says what it is: load demand that the
+    # caches serve (the scene fits the Infinity Cache), not bytes that crossed the HBM interface.
+    res["survey_8d_frac"] = nbytes / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else 0.0
+    res["survey_8d_note"] = "algorithmic_bytes_per_launch / avg_launch_ms / 8 TB/s, the task's definition: non-physical above 1 (cache-served load demand); frac is the measured HBM-side figure"
     # the 8(d) bytes are load demand served by the caches: set against the L2's aggregate bandwidth, never against HBM
     L2_PEAK_GBS = 34500.0           # MI355X_MICROARCH.md: 8 x 4 MiB L2, ~34.5 TB/s aggregate
     res["load_demand"] = {"GB/s": nbytes / sec / 1e9 if sec > 0 else 0.0, "device_layout_GB/s": lbytes / sec / 1e9 if sec > 0 else 0.0,
@@ -582,16 +735,34 @@ def roofline(args, wl, scene, info, ms, rays, frames_per_launch=1):
     if traffic is not None:
         res["traffic_over_compulsory"] = traffic / compulsory
     if "valu_busy" in pmc and "active_lanes" in pmc:
-        res["valu"] = {"bound": "valu", "busy": pmc["valu_busy"], "active_lanes": pmc["active_lanes"],
-                       "frac": pmc["valu_busy"] * pmc["active_lanes"],
+        res["valu"] = {"bound": "valu", "busy": min(1.0, pmc["valu_busy"]), "active_lanes": pmc["active_lanes"],
+                       "frac": min(1.0, pmc["valu_busy"]) * pmc["active_lanes"],
+                       "issue_lower_bound": pmc.get("valu_issue_min"),
+                       "frac_lower_bound": (pmc["valu_issue_min"] * pmc["active_lanes"]) if pmc.get("valu_issue_min") else None,
                        "waves_per_simd": pmc.get("waves_per_simd"), "ta_busy": pmc.get("ta_busy"), "td_busy": pmc.get("td_busy"),
-                       "note": "the bound that binds: share of the kernel's SIMD cycles issuing vector ALU instructions x active lanes "
-                               "per instruction (%s, rocprofv3 --pmc SQ passes of this command with --inflight 1: one call at a time)" % PMC_FILE}
+                       "note": "the bound that binds: share of the kernel's SIMD cycles issuing vector ALU instructions (at most 1) x active lanes "
+                               "per instruction (%s, rocprofv3 --pmc SQ passes of this command with --inflight 1: one call at a time)" % pmc_file}
         res["binding_bound"] = "valu"
     res["rays_entering_bvh_per_frame"] = {k: v * spp for k, v in entering.items()}
-    # the same traversal of the same BVH on the host's cores (the "same algorithm on the CPU" figure of SURVEY 8(d))
-    res["cpu_bvh_traversal"] = {"value": len(pick) / cpu_bvh_s / 1e6, "unit": "Mrays/s (primary)", "cores": threads, "host_cores": cores,
-                                "sample": "every %d-th pixel's primary ray, oracle/rt_oracle_bvh.c" % stride}
+    # The same traversal of the same BVH on the host's cores, a WHOLE frame with its shadow rays (the "same algorithm on
+    # the CPU" figure of SURVEY 8(d)): every pixel's primary ray of the first camera, then the shadow ray of every hit.
+    ocam = oa.make_camera(views[0], W, H)
+    o, d1 = oa.camera_rays(ocam, (0, 0, W, H))
+    t0 = time.perf_counter()
+    t, f, _, _ = oa.bvh_trace(nodes, tris, order, lo, hi, o, d1, threads=threads, nwild=info.nwild)
+    t_prim = time.perf_counter() - t0
+    n_sh, t_sh = 0, 0.0
+    hit = f >= 0
+    if hit.any() and wl["opts"][4]:
+        P, sd1, tmax = shadow_rays_of(wl, o, d1, t, hit)
+        t0 = time.perf_counter()
+        oa.bvh_trace_shadow(nodes, tris, order, lo, hi, P, sd1, tmax, anyhit, threads=threads, nwild=info.nwild)
+        t_sh = (time.perf_counter() - t0) * len(wl["lights"])
+        n_sh = len(P) * len(wl["lights"])
+    res["cpu_bvh_full_frame"] = {"value": (W * H + n_sh) / (t_prim + t_sh) / 1e6, "unit": "Mrays/s (primary + shadow)", "cores": threads, "host_cores": cores,
+                                 "seconds": t_prim + t_sh, "rays": {"primary": W * H, "shadow": n_sh},
+                                 "sample": "the whole frame of the first camera of the launch: %d primary rays + %d shadow rays%s, oracle/rt_oracle_bvh.c walking the "
+                                           "library's own BVH" % (W * H, n_sh, " (first light timed, scaled by the light count)" if len(wl["lights"]) > 1 else "")}
     return res
 
 

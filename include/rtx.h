@@ -185,14 +185,16 @@ int rtx_trace_closest(rtx_scene*, const float* origin_xyz, const float* dir_xyz,
 int rtx_trace_closest_dev(rtx_scene*, const float* origin_xyz, const float* dir_xyz, uint32_t n,
                           float* t, int32_t* face_id);
 
-/* rtx_trace_closest_dev for callers that cannot allocate device memory (code under HIP graph capture,
- * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same
- * kernels and results, but the ray records, hit records and traversal-stack overflow that
- * rtx_trace_closest_dev keeps in the scene's growable workspace live in a fixed device array inside
- * the library (~11.7 MB per GPU, held until the process ends), and the call makes no hipMalloc /
- * hipFree / event creation.  At most RTX_NOALLOC_MAX_RAYS rays per call (RTX_ELIMIT beyond).  All
- * calls on one GPU share that array, whichever scene they name: calls that overlap on a GPU race;
- * serialise them.  Returns when the results are in t / face_id (device pointers, like the inputs). */
+/* rtx_trace_closest_dev for callers that cannot allocate device memory (tight serving loops, harnesses
+ * that forbid hipMalloc).  No counterpart in the reference.  Same kernels and results, but the
+ * ray records, hit records and traversal-stack overflow that rtx_trace_closest_dev keeps in the scene's
+ * growable workspace live in a fixed device array inside the library (~11.7 MB per GPU, held until the
+ * process ends), and the call makes no hipMalloc / hipFree / event creation.  At most RTX_NOALLOC_MAX_RAYS
+ * rays per call (RTX_ELIMIT beyond).  All calls on one GPU share that array, whichever scene they name: calls
+ * that overlap on a GPU race; serialise them.  Returns when the results are in t / face_id (device pointers,
+ * like the inputs): it launches on a stream of the library's own and waits for it, so the call itself cannot
+ * be captured into a graph.  Unlike the other synchronous entry points it leaves enqueued renders in flight
+ * and rtx_get_stats untouched (no events, no counters read back). */
 #define RTX_NOALLOC_MAX_RAYS 65536u
 int rtx_trace_closest_noalloc(rtx_scene*, const float* origin_xyz, const float* dir_xyz, uint32_t n,
                               float* t, int32_t* face_id);
@@ -284,10 +286,12 @@ int rtx_render_tiles_dev_enqueue(rtx_scene*, const rtx_camera*, const rtx_option
                                  int32_t tile_size, int32_t part, int32_t nparts,
                                  float* rgb, float* t, int32_t* face_id);
 
-/* A batch of frames in one call: nframes (1 .. RTX_MAX_BATCH) cameras over the same rectangle and tile partition,
+/* A batch of frames in one call: nframes (1 .. RTX_MAX_BATCH = 64) cameras over the same rectangle and tile partition,
  * traced and shaded by ONE set of kernel launches; frame f's pixels land at rgb + 3 f P, t + f P, face_id + f P with
- * P = rtx_tiles_count(rect, tile_size, part, nparts) * tile_size^2 -- or, with tile_size 0 (part 0 of 1), the whole
- * rectangle row-major and P = its pixels.  Every frame's values are those of rtx_render_tiles_dev (rtx_render_dev)
+ * P = rtx_tiles_count(rect, tile_size, 0, nparts) * tile_size^2 -- the size of the LARGEST part (part 0), the same for
+ * every part, so that the parts of all ranks have one layout [frame][local tile] and gather into one buffer whatever
+ * their own tile counts (slots beyond a part's last tile are left untouched) -- or, with tile_size 0 (part 0 of 1), the
+ * whole rectangle row-major and P = its pixels.  Every frame's values are those of rtx_render_tiles_dev (rtx_render_dev)
  * with that camera, bit for bit.  For the ranks of an N-GPU run: a rank's share of one frame gives its persistent
  * traversal kernels too few rays to run at full rate (1/8 of the 4K soup frame: 0.37 ms instead of 0.23 ms), its
  * share of N frames of an animation gives them as many as one whole frame.  The enqueue form is finished by
@@ -295,7 +299,7 @@ int rtx_render_tiles_dev_enqueue(rtx_scene*, const rtx_camera*, const rtx_option
  * sized for all frames at once -- about 8 + 4 + 40 L bytes per pixel and frame (hit records, parents, L light samples' shadow rays
  * and hits), more with bounces -- per call slot in use: 3.4 GB for 8 frames of 3840x2160 with one light.
  * No counterpart in the reference (raytraceScene renders one camera, src/flyscene.cpp:395-468). */
-#define RTX_MAX_BATCH 16
+#define RTX_MAX_BATCH 64
 int rtx_render_tiles_batch_dev(rtx_scene*, const rtx_camera* cams, int32_t nframes, const rtx_options*, rtx_rect rect,
                                int32_t tile_size, int32_t part, int32_t nparts,
                                float* rgb, float* t, int32_t* face_id);
@@ -310,6 +314,18 @@ int rtx_render_tiles_batch_dev_enqueue(rtx_scene*, const rtx_camera* cams, int32
  * hipStream_t as void*, NULL = default stream) and returns without waiting for it.  No scene needed. */
 int rtx_tiles_assemble_dev(const void* parts, int32_t nparts, uint64_t part_stride_pixels, rtx_rect rect,
                            int32_t tile_size, int32_t words_per_pixel, void* out, void* stream);
+/* ... for pixels of any size in bytes (1 .. 64; 3 for the P3 bytes below): the same call, sizes in bytes. */
+int rtx_tiles_assemble_bytes_dev(const void* parts, int32_t nparts, uint64_t part_stride_pixels, rtx_rect rect,
+                                 int32_t tile_size, int32_t bytes_per_pixel, void* out, void* stream);
+
+/* The quantisation of Tucano::ImageImporter::writePPMImage (dependencies/tucano/tucano/utils/ppmIO.hpp:130-151, called by
+ * raytraceScene, src/flyscene.cpp:433) on the device: out[3 i + c] = min(255, (int)(255 * rgb[3 i + c])) as a byte, for
+ * npixels pixels in whatever order they lie (row-major frames and compact tile buffers alike) -- the numbers result.ppm
+ * holds, bit-equal to quantising the fp32 frame on the host.  What a rank of a multi-GPU run hands over when the frame is
+ * wanted as the reference writes it: 3 bytes per pixel instead of 12.  A channel whose P3 number no byte can hold (the
+ * reference prints a negative number for a negative channel and for NaN / infinities) becomes 0 (255 for +infinity).
+ * Device pointers; runs on `stream` (a hipStream_t as void*, NULL = default stream) without waiting for it.  No scene needed. */
+int rtx_rgb_to_ppm8_dev(const float* rgb, uint64_t npixels, uint8_t* out, void* stream);
 
 /* Several GPUs in one process: Flyscene::raytraceScene's thread decomposition (src/flyscene.cpp:417-430,460:
  * 16 threads striding the rows of one frame) as nscenes parts of the tile grid, part i rendered by scenes[i]

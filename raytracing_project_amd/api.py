@@ -50,13 +50,13 @@ SYMBOLS = ["rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_
            "rtx_scene_add_material", "rtx_scene_set_spheres", "rtx_scene_set_lights", "rtx_scene_build", "rtx_scene_commit",
            "rtx_scene_get_tris",
            "rtx_scene_get_info", "rtx_scene_get_bvh", "rtx_trace_closest", "rtx_trace_closest_dev",
-           "rtx_trace_visible", "rtx_render", "rtx_render_dev", "rtx_render_dev_enqueue", "rtx_render_finish", "rtx_tiles_count", "rtx_render_tiles_dev", "rtx_render_tiles_dev_enqueue", "rtx_render_tiles_batch_dev", "rtx_render_tiles_batch_dev_enqueue", "rtx_tiles_assemble_dev",
+           "rtx_trace_visible", "rtx_render", "rtx_render_dev", "rtx_render_dev_enqueue", "rtx_render_finish", "rtx_tiles_count", "rtx_render_tiles_dev", "rtx_render_tiles_dev_enqueue", "rtx_render_tiles_batch_dev", "rtx_render_tiles_batch_dev_enqueue", "rtx_tiles_assemble_dev", "rtx_tiles_assemble_bytes_dev", "rtx_rgb_to_ppm8_dev",
            "rtx_get_stats", "rtx_scene_build_reference_leafboxes", "rtx_scene_set_leafboxes",
            "rtx_scene_get_leafboxes", "rtx_intersect_box", "rtx_trace_shade", "rtx_camera_points", "rtx_scene_set_flags",
            "rtx_scene_get_packed_bvh", "rtx_debug_hit", "rtx_trace_closest_noalloc", "rtx_scene_clone", "rtx_render_multi",
            "rtx_render_multi_dev", "rtx_intersect_primitive", "rtx_trace_gi"]
 
-MAX_BATCH = 16
+MAX_BATCH = 64
 NOALLOC_MAX_RAYS = 65536
 FLAG_NO_ROOT_GATE, FLAG_SCHED_REFILL, FLAG_SCHED_GROUPS, FLAG_SCHED_SPLIT, FLAG_VERIFY = 1, 2, 4, 8, 16
 
@@ -138,6 +138,8 @@ def lib():
             fn.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int32, C.POINTER(Options), Rect, C.c_int32, C.c_int32, C.c_int32,
                            C.c_void_p, C.c_void_p, C.c_void_p]
         L.rtx_tiles_assemble_dev.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, Rect, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.rtx_tiles_assemble_bytes_dev.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, Rect, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.rtx_rgb_to_ppm8_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -404,6 +406,18 @@ def tiles_assemble_dev(parts_ptr, nparts, part_stride_pixels, rect, tile_size, w
     x0, y0, x1, y1 = rect
     _check(lib().rtx_tiles_assemble_dev(parts_ptr, nparts, part_stride_pixels, Rect(x0, y0, x1, y1), tile_size,
                                         words_per_pixel, out_ptr, stream))
+
+
+def tiles_assemble_bytes_dev(parts_ptr, nparts, part_stride_pixels, rect, tile_size, bytes_per_pixel, out_ptr, stream=None):
+    """rtx_tiles_assemble_bytes_dev: the same for pixels of any size in bytes (3: the P3 bytes of rgb_to_ppm8_dev)."""
+    x0, y0, x1, y1 = rect
+    _check(lib().rtx_tiles_assemble_bytes_dev(parts_ptr, nparts, part_stride_pixels, Rect(x0, y0, x1, y1), tile_size,
+                                              bytes_per_pixel, out_ptr, stream))
+
+
+def rgb_to_ppm8_dev(rgb_ptr, npixels, out_ptr, stream=None):
+    """rtx_rgb_to_ppm8_dev: min(255, (int)(255 c)) per channel (ppmIO.hpp:145) -> 3 bytes per pixel, on `stream` (no wait)."""
+    _check(lib().rtx_rgb_to_ppm8_dev(rgb_ptr, npixels, out_ptr, stream))
 
 
 def render_multi(scenes, cam, opts, rect, tile_size=32, want_rgb=True, want_hits=True):

@@ -237,11 +237,11 @@ namespace {
 //    own two children until four slots are taken -- a leaf child leaves its slot's worth of depth to the other side,
 //    and the big boxes (the ones most rays enter) are the ones opened;
 //  fixed: the children's children (two binary levels per group step, whatever they hold).
-bool g_greedy_collapse = true;
-int group_candidates(const std::vector<BvhNode>& bin, uint32_t b, uint32_t cand[4]) {
+// (the choice travels as an argument: scenes are built independently, possibly on several threads)
+int group_candidates(const std::vector<BvhNode>& bin, uint32_t b, bool greedy, uint32_t cand[4]) {
   int nc = 0;
   const uint32_t kids[2] = {bin[b].leftFirst, bin[b].leftFirst + 1};
-  if (!g_greedy_collapse) {
+  if (!greedy) {
     for (int k = 0; k < 2; ++k) {
       const BvhNode& c = bin[kids[k]];
       if (c.count == 0) { cand[nc++] = c.leftFirst; cand[nc++] = c.leftFirst + 1; }
@@ -267,9 +267,9 @@ int group_candidates(const std::vector<BvhNode>& bin, uint32_t b, uint32_t cand[
   }
   return nc;
 }
-int fill_group(const std::vector<BvhNode>& bin, uint32_t b, std::vector<BvhNode>& q, uint32_t g, uint32_t depth, BvhBuildResult* out,
+int fill_group(const std::vector<BvhNode>& bin, uint32_t b, bool greedy, std::vector<BvhNode>& q, uint32_t g, uint32_t depth, BvhBuildResult* out,
                uint32_t cand[4]) {
-  const int nc = group_candidates(bin, b, cand);
+  const int nc = group_candidates(bin, b, greedy, cand);
   out->quad_depth = std::max(out->quad_depth, depth);
   for (int k = 0; k < 4; ++k) {
     BvhNode s;
@@ -285,14 +285,14 @@ int fill_group(const std::vector<BvhNode>& bin, uint32_t b, std::vector<BvhNode>
   return nc;
 }
 // Depth first below the top levels: a subtree's groups stay together in memory.
-uint32_t collapse_node(const std::vector<BvhNode>& bin, uint32_t b, std::vector<BvhNode>& q, uint32_t depth, BvhBuildResult* out) {
+uint32_t collapse_node(const std::vector<BvhNode>& bin, uint32_t b, bool greedy, std::vector<BvhNode>& q, uint32_t depth, BvhBuildResult* out) {
   uint32_t cand[4];
   const uint32_t g = (uint32_t)(q.size() / 4);
   q.resize(q.size() + 4);
-  const int nc = fill_group(bin, b, q, g, depth, out, cand);
+  const int nc = fill_group(bin, b, greedy, q, g, depth, out, cand);
   for (int k = 0; k < nc; ++k) {
     if (bin[cand[k]].count == 0) {
-      const uint32_t child = collapse_node(bin, cand[k], q, depth + 1, out);
+      const uint32_t child = collapse_node(bin, cand[k], greedy, q, depth + 1, out);
       q[4 * (size_t)g + k].leftFirst = child;
     }
   }
@@ -300,16 +300,15 @@ uint32_t collapse_node(const std::vector<BvhNode>& bin, uint32_t b, std::vector<
 }
 }  // namespace
 
-static void collapse_once(BvhBuildResult* out);
+static void collapse_once(BvhBuildResult* out, bool greedy);
 void collapse_to_quads(BvhBuildResult* out) {
   static const bool fixed = [] { const char* e = std::getenv("RTX_COLLAPSE"); return e && std::strcmp(e, "fixed") == 0; }();   // tuning hook
-  g_greedy_collapse = !fixed;
-  collapse_once(out);
-  // the traversal stack holds 3 entries per group level (rtx.hip checks 3 * quad_depth): a tree the greedy choice
-  // makes too deep in groups is collapsed two binary levels per group instead
-  if (g_greedy_collapse && 3 * out->quad_depth > 48) { g_greedy_collapse = false; collapse_once(out); g_greedy_collapse = true; }
+  collapse_once(out, !fixed);
+  // the traversal stack holds 3 entries per group level (rtx.hip checks 3 * quad_depth against the same constant): a
+  // tree the greedy choice makes too deep in groups is collapsed two binary levels per group instead
+  if (!fixed && 3 * out->quad_depth > (uint32_t)kTraversalStackDepth) collapse_once(out, false);
 }
-static void collapse_once(BvhBuildResult* out) {
+static void collapse_once(BvhBuildResult* out, bool greedy) {
   out->quads.clear(); out->quad_depth = 0; out->quad_slots = 0;
   for (uint32_t& t : out->top_groups) t = 0;
   const std::vector<BvhNode>& bin = out->nodes;
@@ -326,7 +325,7 @@ static void collapse_once(BvhBuildResult* out) {
     for (size_t head = 0; head < fifo.size(); ++head) {
       const Item it = fifo[head];
       uint32_t cand[4];
-      const int nc = fill_group(bin, it.bin_node, q, it.group, it.depth, out, cand);
+      const int nc = fill_group(bin, it.bin_node, greedy, q, it.group, it.depth, out, cand);
       for (int k = 0; k < nc; ++k) {
         if (bin[cand[k]].count != 0) continue;
         if (it.depth < (uint32_t)kTopLevels) {
@@ -343,10 +342,10 @@ static void collapse_once(BvhBuildResult* out) {
     for (const Item& it : fifo) {
       if (it.depth < (uint32_t)kTopLevels) continue;
       uint32_t cand[4];
-      const int nc = group_candidates(bin, it.bin_node, cand);
+      const int nc = group_candidates(bin, it.bin_node, greedy, cand);
       for (int k = 0; k < nc; ++k)
         if (bin[cand[k]].count == 0) {
-          const uint32_t child = collapse_node(bin, cand[k], q, it.depth + 1, out);
+          const uint32_t child = collapse_node(bin, cand[k], greedy, q, it.depth + 1, out);
           q[4 * (size_t)it.group + k].leftFirst = child;
         }
     }

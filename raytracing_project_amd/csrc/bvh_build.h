@@ -35,6 +35,7 @@ struct BvhBuildResult {
   uint32_t max_depth = 0;          // root = depth 0
 };
 
+constexpr int kTraversalStackDepth = 48;   // per-lane traversal stack entries of the kernels (rtx_kernels.h: kStackDepth); <= 3 per group level
 constexpr int kTopLevels = 3;      // levels of groups numbered breadth first (<= 1 + 4 + 16 = 21 groups): the kernels stage them in LDS
 constexpr int kMaxLeafTris = 4;    // fits the 3-bit count of the traversal stack entry (<= 7)
 constexpr int kMaxDepth = 30;      // binary depth; the collapsed tree has <= 15 levels of groups

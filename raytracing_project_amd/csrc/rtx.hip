@@ -18,6 +18,7 @@
 #include "rtx_kernels.h"
 
 using namespace rtx;
+static_assert(kStackDepth == kTraversalStackDepth, "the builder's depth fallback and the kernels' stack must agree");
 
 static thread_local std::string g_err;
 static int fail(int code, const char* fmt, ...) {
@@ -731,7 +732,11 @@ static int size_bucket(uint64_t n0) {
   return std::min(lg / 2, rtx_scene::kBuckets - 1);
 }
 static int stats_begin(rtx_scene* s, uint64_t n0 = 0) {
-  s->cur = (s->cur + 1) % kSlots;          // the slot used longest ago
+  // The slot used longest ago -- unless nothing is in flight or waiting to be handed out: a caller that never enqueues
+  // stays in one slot (one workspace grows instead of four, and the camera tables cached there are found again).
+  bool busy = false;
+  for (const rtx_scene::Call& o : s->calls) busy = busy || o.pending || o.unreported;
+  if (busy) s->cur = (s->cur + 1) % kSlots;
   rtx_scene::Call& c = cur_call(s);
   if (int rc = finish_call(s, c)) return rc;
   c.unreported = false;
@@ -924,19 +929,28 @@ static int guard_queue(rtx_scene* s, const float4* rays, const uint32_t* count, 
                      ws(s).w_guard.as<uint32_t>());
   return RTX_OK;
 }
-static int guard_camera(rtx_scene* s, const DevCamera& C, const DevCamera* cams, uint32_t nframes, uint32_t nslots, uint2* hits) {
-  bool far = false;     // C: frame 0 with the device pointers set; cams: the frames of the batch (host copies)
+static bool camera_beyond_domain(const rtx_scene* s, const DevCamera* cams, uint32_t nframes) {
+  bool far = false;
   for (uint32_t f = 0; f < nframes; ++f) {
-    const float* o = cams ? cams[f].origin : C.origin;
+    const float* o = cams[f].origin;
     far = far || std::max(std::fabs(o[0]), std::max(std::fabs(o[1]), std::fabs(o[2]))) > s->domain;
   }
-  const uint32_t vs = verify_stride(s, nslots);
-  if ((!far && vs == 0) || s->dev.ntris == 0) return RTX_OK;
-  // every pixel of a camera beyond the domain is a brute-force scan: fine for the reference's own scenes, not for millions of triangles
-  if (far && (double)nslots * (double)s->dev.ntris > 7e10)
+  return far;
+}
+// A host-side check, made before the call takes a slot or queues anything: every pixel of a camera beyond the domain is a
+// brute-force scan, fine for the reference's own scenes, not for millions of triangles.
+static int check_camera_domain(const rtx_scene* s, const DevCamera* cams, uint32_t nframes, uint32_t nslots) {
+  if (s->dev.ntris == 0 || !camera_beyond_domain(s, cams, nframes)) return RTX_OK;
+  if ((double)nslots * (double)s->dev.ntris > 7e10)
     return fail(RTX_ELIMIT, "the camera is farther than %g from the origin, beyond what this mesh's culling boxes are padded for, and %u pixels x %u "
                             "triangles is too much to answer by brute force: move the camera closer or render a smaller rectangle", (double)s->domain,
                 nslots, s->dev.ntris);
+  return RTX_OK;
+}
+static int guard_camera(rtx_scene* s, const DevCamera& C, const DevCamera* cams, uint32_t nframes, uint32_t nslots, uint2* hits) {
+  const bool far = camera_beyond_domain(s, cams ? cams : &C, cams ? nframes : 1u);     // C: frame 0 with the device pointers set; cams: the frames of the batch (host copies)
+  const uint32_t vs = verify_stride(s, nslots);
+  if ((!far && vs == 0) || s->dev.ntris == 0) return RTX_OK;
   if (int rc = guard_begin(s)) return rc;
   const uint32_t grid = (uint32_t)std::min<uint64_t>(nslots, (uint64_t)s->ncu * 8);
   hipLaunchKernelGGL(k_guard_camera, dim3(grid), dim3(kBlock), 0, ws(s).stream, s->dev, C, nslots, s->domain, vs, hits, ws(s).w_guard.as<uint32_t>());
@@ -1160,27 +1174,55 @@ extern "C" int rtx_tiles_count(rtx_rect rect, int32_t tile_size, int32_t part, i
 // rtx_render_tiles_dev's layout undone: the compact tile buffers of all parts (one after the other,
 // part_stride_pixels apart) -> the row-major rectangle.  Stateless; runs on `stream` (a hipStream_t, may be
 // null for the default stream) and does not wait for it.
-extern "C" int rtx_tiles_assemble_dev(const void* parts, int32_t nparts, uint64_t part_stride_pixels, rtx_rect rect, int32_t tile_size,
-                                      int32_t words_per_pixel, void* out, void* stream) {
+extern "C" int rtx_tiles_assemble_bytes_dev(const void* parts, int32_t nparts, uint64_t part_stride_pixels, rtx_rect rect, int32_t tile_size,
+                                            int32_t bytes_per_pixel, void* out, void* stream) {
   if (!parts || !out) return fail(RTX_EINVAL, "null buffer");
-  if (words_per_pixel < 1 || words_per_pixel > 16) return fail(RTX_EINVAL, "words_per_pixel must be in [1,16]");
+  if (bytes_per_pixel < 1 || bytes_per_pixel > 64) return fail(RTX_EINVAL, "bytes_per_pixel must be in [1,64]");
   const int kmax = rtx_tiles_count(rect, tile_size, 0, nparts);      // validates rect / tile_size / nparts
   if (kmax < 0) return kmax;
   if (part_stride_pixels < (uint64_t)kmax * tile_size * tile_size) return fail(RTX_EINVAL, "part_stride_pixels smaller than a part");
   const uint32_t w = (uint32_t)(rect.x1 - rect.x0), h = (uint32_t)(rect.y1 - rect.y0);
   if ((uint64_t)w * h >= (1ull << 31)) return fail(RTX_ELIMIT, "rectangle has too many pixels");
-  const uint64_t n = (uint64_t)w * h * (uint32_t)words_per_pixel;
-  const bool aligned16 = (((uintptr_t)parts | (uintptr_t)out) & 15u) == 0 && ((part_stride_pixels * (uint32_t)words_per_pixel) & 3u) == 0;
-  if ((w & 3u) == 0 && aligned16) {
-    const uint32_t grid4 = (uint32_t)std::min<uint64_t>((n / 4 + 255) / 256, 256u * 64u);
+  const uint32_t bpp = (uint32_t)bytes_per_pixel;
+  const uint64_t bytes = (uint64_t)w * h * bpp;
+  const bool aligned16 = (((uintptr_t)parts | (uintptr_t)out) & 15u) == 0 && ((part_stride_pixels * bpp) & 15u) == 0;
+  // (tile sizes are multiples of 16 pixels, so a full tile row is a whole number of 16-byte pieces whatever the pixel size)
+  if (((uint64_t)w * bpp & 15u) == 0 && ((uint64_t)(w % (uint32_t)tile_size) * bpp & 15u) == 0 && aligned16) {
+    const uint32_t grid4 = (uint32_t)std::min<uint64_t>((bytes / 16 + 255) / 256, 256u * 64u);
     hipLaunchKernelGGL(k_assemble_tiles_v4, dim3(grid4), dim3(256), 0, (hipStream_t)stream, (const uint4*)parts, (uint32_t)nparts,
-                       part_stride_pixels * (uint32_t)words_per_pixel / 4, w, h, (uint32_t)tile_size, (uint32_t)words_per_pixel, (uint4*)out);
+                       part_stride_pixels * bpp / 16, w, h, (uint32_t)tile_size, bpp, (uint4*)out);
     HIP_TRY(hipGetLastError());
     return RTX_OK;
   }
+  const bool words = (bpp & 3u) == 0 && (((uintptr_t)parts | (uintptr_t)out) & 3u) == 0;
+  const uint64_t n = words ? bytes / 4 : bytes;
   const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256u * 64u);
-  hipLaunchKernelGGL(k_assemble_tiles, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)parts, (uint32_t)nparts,
-                     part_stride_pixels * (uint32_t)words_per_pixel, w, h, (uint32_t)tile_size, (uint32_t)words_per_pixel, (uint32_t*)out);
+  if (words)
+    hipLaunchKernelGGL(k_assemble_tiles<uint32_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)parts, (uint32_t)nparts,
+                       part_stride_pixels * (bpp / 4), w, h, (uint32_t)tile_size, bpp / 4, (uint32_t*)out);
+  else
+    hipLaunchKernelGGL(k_assemble_tiles<uint8_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)parts, (uint32_t)nparts,
+                       part_stride_pixels * bpp, w, h, (uint32_t)tile_size, bpp, (uint8_t*)out);
+  HIP_TRY(hipGetLastError());
+  return RTX_OK;
+}
+extern "C" int rtx_tiles_assemble_dev(const void* parts, int32_t nparts, uint64_t part_stride_pixels, rtx_rect rect, int32_t tile_size,
+                                      int32_t words_per_pixel, void* out, void* stream) {
+  if (words_per_pixel < 1 || words_per_pixel > 16) return fail(RTX_EINVAL, "words_per_pixel must be in [1,16]");
+  return rtx_tiles_assemble_bytes_dev(parts, nparts, part_stride_pixels, rect, tile_size, 4 * words_per_pixel, out, stream);
+}
+
+// ppmIO.hpp:145's quantisation of a frame (any layout: it works value by value), so that what leaves a rank is the
+// 3 bytes per pixel the reference writes to result.ppm instead of 12.  Stateless, like the assemble call.
+extern "C" int rtx_rgb_to_ppm8_dev(const float* rgb, uint64_t npixels, uint8_t* out, void* stream) {
+  if (npixels == 0) return RTX_OK;
+  if (!rgb || !out) return fail(RTX_EINVAL, "null buffer");
+  if (npixels >= (1ull << 40)) return fail(RTX_ELIMIT, "too many pixels");
+  const uint64_t n = npixels * 3;
+  const bool aligned = ((uintptr_t)rgb & 15u) == 0 && ((uintptr_t)out & 3u) == 0;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(((aligned ? n / 4 : n) + 255) / 256 + 1, 256u * 32u);
+  if (aligned) hipLaunchKernelGGL(k_rgb_to_ppm8, dim3(grid), dim3(256), 0, (hipStream_t)stream, rgb, n, out);
+  else hipLaunchKernelGGL(k_rgb_to_ppm8_unaligned, dim3(grid), dim3(256), 0, (hipStream_t)stream, rgb, n, out);
   HIP_TRY(hipGetLastError());
   return RTX_OK;
 }
@@ -1215,7 +1257,12 @@ static int render_tiles_impl(rtx_scene* s, const rtx_camera* cams, int32_t nfram
     npix = (uint64_t)C[0].w * (uint64_t)C[0].h;
     nblocks = (uint64_t)((C[0].w + 15) / 16) * (uint64_t)((C[0].h + 15) / 16);
   } else {
-    npix = (uint64_t)nt * (uint64_t)(tile_size * tile_size);
+    // Frames of a batch lie one largest-part apart (part 0 owns the most tiles): every part of a partition then has the
+    // same layout [frame][local tile], whatever its own tile count, and the parts of all ranks gather into one buffer.
+    // The slots between a part's last tile and the next frame are dead (never read or written), like those of partial
+    // edge tiles.
+    const int kmax = nframes > 1 ? rtx_tiles_count(rect, tile_size, 0, nparts) : nt;
+    npix = (uint64_t)kmax * (uint64_t)(tile_size * tile_size);
     nblocks = (uint64_t)nt * (uint64_t)((tile_size / 16) * (tile_size / 16));
   }
   if (npix * (uint64_t)nframes >= (1ull << 31) || nblocks * (uint64_t)nframes >= (1ull << 31) / 256)
@@ -1397,6 +1444,7 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
 
 static int render_impl(rtx_scene* s, const DevCamera* cams, uint32_t nframes, uint32_t npix, uint32_t tiles, const rtx_options* opt,
                        float* rgb, float* t, int32_t* face, bool wait) {
+  if (int rc = check_camera_domain(s, cams, nframes, npix)) return rc;
   if (int rc = stats_begin(s, npix)) return rc;
   cur_call(s).throughput = !wait && !cur_call(s).alone;
   cur_call(s).tunable = true;
@@ -1415,14 +1463,15 @@ static int render_impl(rtx_scene* s, const DevCamera* cams, uint32_t nframes, ui
     for (uint32_t f = 0; f < nframes; ++f)
       hipLaunchKernelGGL(k_camera_tables, dim3((uint32_t)(tab_words + 255) / 256), dim3(256), 0, ws(s).stream, cams[f],
                          ws(s).w_cam_tab.as<float>() + tab_words * f);
-    if (nframes > 1) {
+    for (uint32_t f0 = 0; nframes > 1 && f0 < nframes; f0 += kFramesPerStore) {
       FrameBatch B;
       std::memset(&B, 0, sizeof B);
-      for (uint32_t f = 0; f < nframes; ++f) {
-        std::memcpy(B.rec[f], cams[f].inv34, 12 * sizeof(float));
-        std::memcpy(B.rec[f] + 12, cams[f].origin, 3 * sizeof(float));
+      const uint32_t nf = std::min<uint32_t>(kFramesPerStore, nframes - f0);
+      for (uint32_t f = 0; f < nf; ++f) {
+        std::memcpy(B.rec[f], cams[f0 + f].inv34, 12 * sizeof(float));
+        std::memcpy(B.rec[f] + 12, cams[f0 + f].origin, 3 * sizeof(float));
       }
-      hipLaunchKernelGGL(k_store_frames, dim3(1), dim3(16 * kMaxBatch), 0, ws(s).stream, B, nframes, ws(s).w_frames.as<float>());
+      hipLaunchKernelGGL(k_store_frames, dim3(1), dim3(16 * kFramesPerStore), 0, ws(s).stream, B, nf, ws(s).w_frames.as<float>() + 16u * f0);
     }
     held.assign(cams, cams + nframes); ws(s).cam_tab_ok = true;
   }
@@ -1709,19 +1758,28 @@ static int render_multi(rtx_scene* const* scenes, int32_t n, const rtx_camera* c
   // every part at once: the calls only queue work
   int first_err = RTX_OK;
   int queued = 0;
+  int slot_of[64];                                     // the call slot part i went to on its scene
   for (int i = 0; i < n && first_err == RTX_OK; ++i) {
     first_err = render_tiles_impl(scenes[i], cam, 1, opt, rect, tile_size, i, n, (float*)part_ptr(i, 0), (float*)part_ptr(i, 1),
                                   (int32_t*)part_ptr(i, 2), false);
-    if (first_err == RTX_OK) ++queued;
+    if (first_err == RTX_OK) { slot_of[i] = scenes[i]->cur; ++queued; }
   }
   std::string err = first_err ? g_err : std::string();
-  for (int i = 0; i < queued; ++i) {                   // (also after an error: nothing stays in flight)
-    const int rc = rtx_render_finish(scenes[i], nullptr);
+  // Wait for exactly the calls queued above (also after an error: nothing of this function stays in flight).  Not
+  // rtx_render_finish: that hands out the OLDEST unreported call of a handle, which is the caller's own when the caller
+  // still has an enqueued render on it -- the part would then be copied before it was rendered, and the caller's
+  // enqueue / finish pairs would be off by one from here on.
+  for (int i = 0; i < queued; ++i) {
+    rtx_scene::Call& c = scenes[i]->calls[slot_of[i]];
+    int rc = RTX_OK;
+    if (hipSetDevice(scenes[i]->device) != hipSuccess) rc = fail(RTX_EHIP, "hipSetDevice(%d)", scenes[i]->device);
+    else rc = finish_call(scenes[i], c);
+    c.unreported = false;
     if (rc && !first_err) { first_err = rc; err = g_err; }
   }
   if (first_err) { g_err = err; return first_err; }
   HIP_TRY(hipSetDevice(s0->device));
-  hipStream_t st = ws(s0).stream;
+  hipStream_t st = scenes[0]->slots[slot_of[0]].stream;
   for (int i = 1; i < n; ++i) {
     if (scenes[i]->device == s0->device) continue;
     for (int c = 0; c < 3; ++c) {

@@ -37,7 +37,8 @@
 namespace rtx {
 
 constexpr int kBlock = 256;          // 4 waves of 64
-constexpr int kStackDepth = 48;      // per-lane traversal stack entries in total (<= 3 per level of 4-node groups, <= 15 levels)
+constexpr int kStackDepth = 48;      // per-lane traversal stack entries in total (<= 3 per level of 4-node groups, <= 15 levels);
+                                     // rtx.hip asserts it equals bvh_build.h's kTraversalStackDepth, which the builder's depth fallback uses
 constexpr int kLdsStackGroups = 16;  // same for the group-by-group scheduler, which parks nothing
 // Node groups of the top levels of the hierarchy kept in LDS per block (64 B each; 21 = three levels, 5 = two, 0 = none),
 // per scheduler.  Measured: the group-by-group kernels, whose 64 rays start at the root together, issue 10 %
@@ -256,8 +257,9 @@ __global__ void k_camera_tables(DevCamera C, float* tab) {
   else if (i < C.w + C.h) tab[i] = camera_ny(C, (float)(C.y0 + (i - C.w)) + C.sub[1]);
 }
 // The per-frame records of a batch travel as kernel arguments (no host buffer to keep alive behind an async copy).
-constexpr int kMaxBatch = 16;
-struct FrameBatch { float rec[kMaxBatch][16]; };
+constexpr int kMaxBatch = 64;
+constexpr int kFramesPerStore = 16;       // records per k_store_frames launch (1 KB of kernel arguments)
+struct FrameBatch { float rec[kFramesPerStore][16]; };
 __global__ void k_store_frames(FrameBatch B, uint32_t n, float* dst) {
   const uint32_t i = threadIdx.x;
   if (i < 16u * n) dst[i] = B.rec[i >> 4][i & 15];
@@ -854,27 +856,29 @@ __global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_tra
 
 // The inverse of the tiled-compact layout: parts[p][k * ts * ts + (y % ts) * ts + (x % ts)][c] of every
 // part p -> out[y][x][c]; tile g = (y / ts) * tiles_x + (x / ts) is local tile g / nparts of part g % nparts.
-// One 32-bit word per thread: consecutive threads read and write consecutive words within a tile row.
-__global__ void k_assemble_tiles(const uint32_t* parts, uint32_t nparts, uint64_t part_stride_words, uint32_t w, uint32_t h,
-                                 uint32_t ts, uint32_t words, uint32_t* out) {
-  const uint64_t n = (uint64_t)w * h * words;
+// One element (a 32-bit word, or a byte for pixel sizes that are not whole words: the 3-byte P3 pixels) per thread:
+// consecutive threads read and write consecutive elements within a tile row.
+template <class T>
+__global__ void k_assemble_tiles(const T* parts, uint32_t nparts, uint64_t part_stride_elems, uint32_t w, uint32_t h,
+                                 uint32_t ts, uint32_t elems, T* out) {
+  const uint64_t n = (uint64_t)w * h * elems;
   const uint32_t tiles_x = (w + ts - 1) / ts;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t pix = (uint32_t)(i / words), c = (uint32_t)(i - (uint64_t)pix * words);
+    const uint32_t pix = (uint32_t)(i / elems), c = (uint32_t)(i - (uint64_t)pix * elems);
     const uint32_t y = pix / w, x = pix - y * w;
     const uint32_t g = (y / ts) * tiles_x + (x / ts);
     const uint32_t p = g % nparts, k = g / nparts;
-    const uint64_t src = (uint64_t)p * part_stride_words + ((uint64_t)k * ts * ts + (uint64_t)(y % ts) * ts + (x % ts)) * words + c;
+    const uint64_t src = (uint64_t)p * part_stride_elems + ((uint64_t)k * ts * ts + (uint64_t)(y % ts) * ts + (x % ts)) * elems + c;
     out[i] = parts[src];
   }
 }
 
-// The same, 16 bytes per thread, for widths that are multiples of 4 pixels (every tile row then is a whole
-// number of 16-byte pieces, aligned in both buffers because tile sizes are multiples of 16 pixels).
-// Thread -> (row y, piece q of that row); a row has w * words / 4 pieces.
+// The same, 16 bytes per thread, where every image row and every tile row is a whole number of 16-byte pieces
+// (w * bytes-per-pixel and ts * bytes-per-pixel multiples of 16: any pixel size at widths that are multiples of 16,
+// since tile sizes are) and both buffers are 16-byte aligned.  Thread -> (row y, piece q of that row).
 __global__ void k_assemble_tiles_v4(const uint4* parts, uint32_t nparts, uint64_t part_stride_v4, uint32_t w, uint32_t h,
-                                    uint32_t ts, uint32_t words, uint4* out) {
-  const uint32_t row_v4 = w * words / 4u, tile_v4 = ts * words / 4u;      // pieces per image row / per full tile row
+                                    uint32_t ts, uint32_t bpp, uint4* out) {
+  const uint32_t row_v4 = w * bpp / 16u, tile_v4 = ts * bpp / 16u;      // pieces per image row / per full tile row
   const uint32_t tiles_x = (w + ts - 1) / ts;
   const uint64_t n = (uint64_t)row_v4 * h;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -885,6 +889,27 @@ __global__ void k_assemble_tiles_v4(const uint4* parts, uint32_t nparts, uint64_
     const uint64_t src = (uint64_t)p * part_stride_v4 + ((uint64_t)k * ts + (y % ts)) * tile_v4 + r;
     out[i] = parts[src];
   }
+}
+
+// The channel values Tucano::ImageImporter::writePPMImage prints (tucano/utils/ppmIO.hpp:145): min(255, (int)(255 * c)),
+// the product in fp32, the conversion truncating -- as a byte.  Where the reference's text holds a number no byte can
+// (a negative channel prints negative; NaN and infinities convert to INT_MIN on x86) the byte is 0, or 255 for +inf.
+__device__ __forceinline__ uint32_t ppm8(float c) {
+  const float v = 255.0f * c;
+  if (!(v >= 1.0f)) return 0u;              // [0, 1) truncates to 0; negatives and NaN have no byte value
+  return v >= 255.0f ? 255u : (uint32_t)(int)v;
+}
+// n channel values (3 per pixel) -> bytes; four per thread where the count allows (float4 in, one word out).
+__global__ void k_rgb_to_ppm8(const float* rgb, uint64_t n, uint8_t* out) {
+  const uint64_t n4 = n / 4;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * blockDim.x) {
+    const float4 v = ((const float4*)rgb)[i];
+    ((uint32_t*)out)[i] = ppm8(v.x) | (ppm8(v.y) << 8) | (ppm8(v.z) << 16) | (ppm8(v.w) << 24);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (uint32_t)(n - 4 * n4)) out[4 * n4 + threadIdx.x] = (uint8_t)ppm8(rgb[4 * n4 + threadIdx.x]);
+}
+__global__ void k_rgb_to_ppm8_unaligned(const float* rgb, uint64_t n, uint8_t* out) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = (uint8_t)ppm8(rgb[i]);
 }
 
 // Ray ctor over caller rays (src/Ray.h:15-18): xyz arrays -> queue records.

@@ -124,6 +124,17 @@ def look_at_view(eye, target, up=(0.0, 1.0, 0.0)):
     return np.concatenate([R, t[:, None]], 1).astype(np.float32)
 
 
+def orbit_view(eye, target, k, step_deg=0.25):
+    """Frame k of a camera path: `eye` turned about the vertical axis through `target` by k * step_deg degrees
+    (frame 0 = look_at_view(eye, target)); what bench.py renders as consecutive frames of an animation."""
+    eye = np.asarray(eye, np.float64)
+    target = np.asarray(target, np.float64)
+    a = np.deg2rad(step_deg * k)
+    c, s = np.cos(a), np.sin(a)
+    r = eye - target
+    return look_at_view(target + np.array([c * r[0] + s * r[2], r[1], -s * r[0] + c * r[2]]), target)
+
+
 def default_view():
     """Tucano::Flycamera default: identity rotation, translation (0,0,-2)
     (dependencies/tucano/tucano/utils/flycamera.hpp:76-86,166-191) -> centre (0,0,2)."""

@@ -177,8 +177,9 @@ def main():
         rgb2, tt2, ff2 = s.render(api.make_camera(view2, res, res), api.Options(*opts), (0, 0, res, res))
         ts, nparts = [(0, 1), (16, 1), (16, 3), (32, 2)][int(rng.integers(0, 4))]
         part = int(rng.integers(0, nparts))
-        P = res * res if ts == 0 else api.lib().rtx_tiles_count(api.Rect(0, 0, res, res), ts, part, nparts) * ts * ts
-        if P:
+        # frames of a batch lie one LARGEST part (part 0) apart, whichever part renders
+        P = res * res if ts == 0 else api.lib().rtx_tiles_count(api.Rect(0, 0, res, res), ts, 0, nparts) * ts * ts
+        if P and (ts == 0 or api.lib().rtx_tiles_count(api.Rect(0, 0, res, res), ts, part, nparts) > 0):
             cams = [api.make_camera(view, res, res), api.make_camera(view2, res, res), api.make_camera(view, res, res)]
             b_rgb = torch.zeros((3 * P, 3), dtype=torch.float32, device="cuda")
             b_t = torch.zeros((3 * P,), dtype=torch.float32, device="cuda")

@@ -60,7 +60,17 @@ def main():
             if g("SQ_BUSY_CYCLES") and g("SQ_INSTS_VALU"):
                 busy = g("SQ_BUSY_CYCLES") / NSE
                 rec["valu_insts"] = g("SQ_INSTS_VALU")
-                rec["valu_busy"] = 4.0 * g("SQ_ACTIVE_INST_VALU") / (NSIMD * busy)
+                # Two estimators of "share of the kernel's SIMD cycles issuing vector ALU instructions":
+                #  * SQ_ACTIVE_INST_VALU (quad-cycles waves spent executing VALU) over the shader engines' busy cycles: it
+                #    saturates -- and, being normalised by the SE's busy time rather than each SIMD's, overshoots 1 by a few
+                #    per cent on a saturated kernel (1.06 on the hall's camera kernel) -- so it is clamped: 1.0 = saturated;
+                #  * 4 cycles (the issue time of a wave64 fp32 instruction on a 16-lane SIMD; longer ones exist) x
+                #    SQ_INSTS_VALU over SIMDs x the kernel's own cycles (GRBM_GUI_ACTIVE per XCD): a lower bound that
+                #    cannot exceed 1.
+                rec["valu_busy_raw"] = 4.0 * g("SQ_ACTIVE_INST_VALU") / (NSIMD * busy)
+                rec["valu_busy"] = min(1.0, rec["valu_busy_raw"])
+                if g("GRBM_GUI_ACTIVE"):
+                    rec["valu_issue_min"] = 4.0 * g("SQ_INSTS_VALU") / (NSIMD * g("GRBM_GUI_ACTIVE") / NXCD)
                 if g("SQ_THREAD_CYCLES_VALU"):
                     rec["active_lanes"] = g("SQ_THREAD_CYCLES_VALU") / (64 * g("SQ_INSTS_VALU"))
                 if g("SQ_WAVE_CYCLES"):
@@ -97,7 +107,10 @@ def main():
         if g("SQ_BUSY_CYCLES") is None or g("SQ_INSTS_VALU") is None:
             continue
         busy = g("SQ_BUSY_CYCLES") / NSE          # cycles the kernel kept a shader engine busy
-        line = "%-24s VALU insts %.4g, VALU busy %.1f %% of SIMD cycles" % (k[:24], g("SQ_INSTS_VALU"), 400.0 * g("SQ_ACTIVE_INST_VALU") / (NSIMD * busy))
+        line = "%-24s VALU insts %.4g, VALU busy %.1f %% of SIMD cycles%s" % (k[:24], g("SQ_INSTS_VALU"), min(100.0, 400.0 * g("SQ_ACTIVE_INST_VALU") / (NSIMD * busy)),
+                                                                             " (estimator saturated: raw %.1f %%)" % (400.0 * g("SQ_ACTIVE_INST_VALU") / (NSIMD * busy)) if 4.0 * g("SQ_ACTIVE_INST_VALU") > NSIMD * busy else "")
+        if g("GRBM_GUI_ACTIVE"):
+            line += ", VALU issue >= %.1f %% (4 cycles x instructions / SIMD cycles of the kernel)" % (400.0 * g("SQ_INSTS_VALU") / (NSIMD * g("GRBM_GUI_ACTIVE") / NXCD))
         if g("SQ_THREAD_CYCLES_VALU"):
             line += ", active lanes %.1f %%" % (100.0 * g("SQ_THREAD_CYCLES_VALU") / (64 * g("SQ_INSTS_VALU")))
         if g("SQ_WAVE_CYCLES"):

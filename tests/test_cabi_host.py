@@ -23,7 +23,7 @@ def api():
 
 def test_library_exports_every_declared_symbol(api):
     hdr = open(os.path.join(ROOT, "include", "rtx.h")).read()
-    declared = sorted(set(re.findall(r"\b(rtx_[a-z_]+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(rtx_[a-z0-9_]+)\s*\(", hdr)))
     assert len(declared) >= 15
     L = api.lib()
     for name in declared:

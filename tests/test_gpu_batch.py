@@ -39,8 +39,10 @@ def test_batch_frames_equal_single_frames(api, scene_name, opts_t):
         return (torch.full((n, 3), -7.0, dtype=torch.float32, device=dev), torch.full((n,), -7.0, dtype=torch.float32, device=dev),
                 torch.full((n,), -9, dtype=torch.int32, device=dev))
 
-    for ts, part, nparts in ((32, 1, 3), (16, 0, 1), (32, 2, 8), (0, 0, 1)):
+    # (32, 1, 2) and (16, 6, 7): parts that own one tile fewer than part 0 -- their frames still lie one LARGEST part apart
+    for ts, part, nparts in ((32, 1, 3), (16, 0, 1), (32, 2, 8), (0, 0, 1), (32, 1, 2), (16, 6, 7)):
         P = W * H if ts == 0 else api.lib().rtx_tiles_count(api.Rect(*rect), ts, part, nparts) * ts * ts
+        P0 = W * H if ts == 0 else api.lib().rtx_tiles_count(api.Rect(*rect), ts, 0, nparts) * ts * ts
         singles = []
         for cam in cams:
             rgb, t, face = bufs(P)
@@ -50,21 +52,26 @@ def test_batch_frames_equal_single_frames(api, scene_name, opts_t):
             else:
                 s.render_tiles_dev(cam, opts, rect, ts, part, nparts, rgb.data_ptr(), t.data_ptr(), face.data_ptr())
             singles.append((rgb.cpu().numpy(), t.cpu().numpy(), face.cpu().numpy(), s.stats()))
-        for F in (1, 2, 5):
-            rgb, t, face = bufs(F * P)
+        # (37 frames: the per-frame records go to the device 16 per launch -- two full launches and a part of a third)
+        for F in (1, 2, 5) + ((37,) if (ts, part) == (32, 1) else ()):
+            stride = P0 if F > 1 else P            # (a batch of one is the single call)
+            rgb, t, face = bufs(F * stride)
             torch.cuda.synchronize()
-            s.render_tiles_batch_dev(cams[:F], opts, rect, ts, part, nparts, rgb.data_ptr(), t.data_ptr(), face.data_ptr())
+            s.render_tiles_batch_dev((cams * 8)[:F], opts, rect, ts, part, nparts, rgb.data_ptr(), t.data_ptr(), face.data_ptr())
             st = s.stats()
-            rgb, t, face = rgb.cpu().numpy().reshape(F, P, 3), t.cpu().numpy().reshape(F, P), face.cpu().numpy().reshape(F, P)
+            rgb, t, face = rgb.cpu().numpy().reshape(F, stride, 3), t.cpu().numpy().reshape(F, stride), face.cpu().numpy().reshape(F, stride)
+            assert (face[:, P:] == -9).all() and (t[:, P:] == -7.0).all() and (rgb[:, P:] == -7.0).all()      # the slots no tile of this part owns
+            rgb, t, face = rgb[:, :P], t[:, :P], face[:, :P]
             for f in range(F):
                 what = "%s frame %d of %d, tile %d part %d/%d" % (scene_name, f, F, ts, part, nparts)
-                assert np.array_equal(face[f], singles[f][2]), what
-                assert_bits_equal(t[f], singles[f][1], "t " + what)
-                assert_bits_equal(rgb[f], singles[f][0], "rgb " + what)
+                one = singles[f % len(cams)]
+                assert np.array_equal(face[f], one[2]), what
+                assert_bits_equal(t[f], one[1], "t " + what)
+                assert_bits_equal(rgb[f], one[0], "rgb " + what)
             # the batch's statistics count the rays of all its frames
-            assert st.rays_primary == sum(x[3].rays_primary for x in singles[:F])
-            assert st.rays_shadow == sum(x[3].rays_shadow for x in singles[:F])
-            assert st.rays_reflection == sum(x[3].rays_reflection for x in singles[:F])
+            assert st.rays_primary == sum(singles[f % len(cams)][3].rays_primary for f in range(F))
+            assert st.rays_shadow == sum(singles[f % len(cams)][3].rays_shadow for f in range(F))
+            assert st.rays_reflection == sum(singles[f % len(cams)][3].rays_reflection for f in range(F))
     # enqueue form: two batches in flight with different cameras, finished in order
     P = api.lib().rtx_tiles_count(api.Rect(*rect), 32, 0, 2) * 32 * 32
     a, b = bufs(3 * P), bufs(2 * P)
@@ -81,8 +88,8 @@ def test_batch_frames_equal_single_frames(api, scene_name, opts_t):
         assert torch.equal(got[0][0].view(-1, P, 3)[got[1]].view(torch.int32), rgb.view(torch.int32))
     assert sa.rays_primary * 2 == sb.rays_primary * 3
     # limits and argument checks
-    with pytest.raises(api.RtxError, match="1 to 16 frames"):
-        s.render_tiles_batch_dev(cams * 4, opts, rect, 32, 0, 2, a[0].data_ptr(), None, None)
+    with pytest.raises(api.RtxError, match="1 to 64 frames"):
+        s.render_tiles_batch_dev(cams * 13, opts, rect, 32, 0, 2, a[0].data_ptr(), None, None)
     with pytest.raises(api.RtxError, match="part 0 of 1"):
         s.render_tiles_batch_dev(cams[:2], opts, rect, 0, 1, 2, a[0].data_ptr(), None, None)
     s.close()

@@ -52,6 +52,22 @@ def test_render_multi_equals_single_scene_frame(api):
     small = s.render(api.make_camera(fx["view_oblique"], 40, 20), opts, (0, 0, 40, 20))
     rgb, t, face = api.render_multi([s] + clones, api.make_camera(fx["view_oblique"], 40, 20), opts, (0, 0, 40, 20), 32)
     assert np.array_equal(face, small[2]) and np.array_equal(rgb.view(np.uint32), small[0].view(np.uint32))
+    # a caller's own enqueued render on one of the handles stays the caller's: rtx_render_multi waits for the parts it
+    # queued itself (not for "the oldest unreported call"), and the caller's enqueue / finish pair still matches up
+    mine = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for victim in (s, clones[0]):
+        mine.zero_()
+        torch.cuda.synchronize()
+        victim.render_dev_enqueue(cam, opts, (0, 0, W, H), mine.data_ptr(), None, None)
+        rgb, t, face = api.render_multi([s] + clones[:2], cam, opts, (0, 0, W, H), 32)
+        assert np.array_equal(face, full[2])
+        assert_bits_equal(rgb, full[0], "rgb of render_multi behind a caller's enqueued frame")
+        st = victim.render_finish()
+        assert st.rays_primary == W * H            # the caller's call (a whole frame), not one of the parts
+        assert_bits_equal(mine.cpu().numpy(), full[0], "the caller's enqueued frame")
+        with pytest.raises(api.RtxError, match="no enqueued render call"):
+            victim.render_finish()
     # every part needs a handle of its own; a clone that was never committed is refused
     with pytest.raises(api.RtxError, match="handle of its own"):
         api.render_multi([s, s], cam, opts, (0, 0, W, H), 32)

@@ -1,0 +1,206 @@
+"""What leaves a rank of a multi-GPU run: the frame as the reference writes it to result.ppm (3 bytes per pixel,
+rtx_rgb_to_ppm8_dev = ppmIO.hpp:145's min(255, (int)(255 c))) through the tile gather (rtx_tiles_assemble_bytes_dev),
+and the gather itself done by two real ranks with PRODUCT pixels (both on GPU 0, gloo through host memory: RCCL
+refuses two ranks on one device) -- every reassembled frame bit-equal to the one-GPU frame."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal, load_scene_fixture, rtx_materials
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def api():
+    from raytracing_project_amd import api
+    assert api.lib().rtx_device_count() >= 1, "no GPU visible: the HIP path cannot run (there is no fallback)"
+    return api
+
+
+def ppm8_numpy(x):
+    """min(255, (int)(255 * c)) with the fp32 product and C's truncation; a number no byte holds -> 0 (255 for +inf)."""
+    v = (np.float32(255.0) * x.astype(np.float32)).astype(np.float32)
+    out = np.zeros(v.shape, np.uint8)
+    ok = v >= 1.0                                   # False for NaN
+    with np.errstate(invalid="ignore"):
+        out[ok] = np.minimum(255.0, np.trunc(np.where(ok, np.minimum(v, 1e6), 0.0)))[ok].astype(np.uint8)
+    return out
+
+
+def test_rgb_to_ppm8_values(api):
+    import torch
+    rng = np.random.default_rng(8)
+    special = np.float32([0.0, -0.0, 1.0, 0.999, 254.5 / 255, 254.999 / 255, 1.0 / 255, 0.0039, 0.00393, 2.0, 300.0, -0.1, -5.0,
+                          np.nan, np.inf, -np.inf, 1e-30, 1e30, 0.5, 0.25])
+    for npix, off in ((1, 0), (5, 0), (1024, 0), (4099, 0), (4099, 1), (333, 3)):
+        x = (rng.random(3 * npix + 4) * 1.3 - 0.15).astype(np.float32)
+        x[rng.integers(0, len(x), min(len(x), 64))] = rng.choice(special, min(len(x), 64))
+        # nextafter neighbours of every k / 255 boundary: the truncation must fall on the reference's side
+        k = rng.integers(1, 256, min(len(x), 96)).astype(np.float32) / np.float32(255)
+        x[: len(k)] = np.nextafter(k, rng.choice(np.float32([-1, 2]), len(k))).astype(np.float32)[: len(x)]
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.full((3 * npix + 8,), 77, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        # off: element offsets that break the 16-byte (input) / 4-byte (output) alignment of the fast path
+        api.rgb_to_ppm8_dev(d_in.data_ptr() + 4 * off, npix, d_out.data_ptr() + off, None)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        want = ppm8_numpy(x[off: off + 3 * npix])
+        assert np.array_equal(got[off: off + 3 * npix], want), (npix, off)
+        assert (got[:off] == 77).all() and (got[off + 3 * npix:] == 77).all()       # nothing written outside
+
+
+def _scene(api, name="spheres"):
+    fx = load_scene_fixture(name)
+    s = api.Scene(fx["verts"], fx["idx"], fx["tri_mat"], rtx_materials(fx["mats"]))
+    s.set_lights([[-1.0, 1.0, 1.0], [1.0, 2.0, 0.5]])
+    s.commit(0)
+    return s, fx
+
+
+def test_ppm8_frame_equals_the_reference_writers_numbers(api, tmp_path):
+    """A rendered square frame, quantised on the GPU, against the text the reference's own writePPMImage produces for
+    the fp32 frame (oracle/_ref, built from /root/reference and shipped prebuilt; the oracle's writer where it is absent)."""
+    import torch
+    from oracle import oracle_api as oa
+    s, fx = _scene(api)
+    n = 96
+    cam = api.make_camera(fx["view_oblique"], n, n)
+    rgb, _, _ = s.render(cam, api.Options(2, 1, 0, 0, 1, 0), (0, 0, n, n))
+    p = tmp_path / "ref.ppm"
+    R = oa.ref()
+    if R is not None and hasattr(R, "ref_write_ppm"):
+        oa.ref_write_ppm(p, rgb)
+    else:
+        assert oa.lib().ora_ppm_write(str(p).encode(), oa.fp(np.ascontiguousarray(rgb)), n, n, 0) == 0
+    tok = open(p).read().split()
+    assert tok[:4] == ["P3", str(n), str(n), "255"]
+    want = np.array(tok[4:], np.int64).reshape(n, n, 3)
+    assert want.min() >= 0 and want.max() == 255 and len(np.unique(want)) > 100
+    d_in = torch.from_numpy(np.ascontiguousarray(rgb)).cuda()
+    d_out = torch.zeros((n, n, 3), dtype=torch.uint8, device="cuda")
+    api.rgb_to_ppm8_dev(d_in.data_ptr(), n * n, d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy().astype(np.int64), want)
+    s.close()
+
+
+@pytest.mark.parametrize("W,H,ts,nparts", [(150, 83, 32, 3), (160, 96, 32, 2), (160, 96, 16, 5), (3840, 64, 32, 8), (52, 40, 16, 1)])
+def test_tile_parts_as_p3_bytes_reassemble_to_the_quantised_frame(api, W, H, ts, nparts):
+    """Every part rendered compact (rtx_render_tiles_dev), quantised where it lies, put back into row-major order as
+    3-byte pixels: equal to the quantised full frame -- through the 16-byte path (widths that are multiples of 16) and
+    the byte path (any width)."""
+    import torch
+    s, fx = _scene(api)
+    cam = api.make_camera(fx["view_oblique"], W, H)
+    opts = api.Options(1, 1, 0, 0, 1, 0)
+    rect = (0, 0, W, H)
+    full = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    s.render_dev(cam, opts, rect, full.data_ptr(), None, None)
+    want = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    api.rgb_to_ppm8_dev(full.data_ptr(), W * H, want.data_ptr(), None)
+    kmax = api.lib().rtx_tiles_count(api.Rect(*rect), ts, 0, nparts)
+    P = kmax * ts * ts
+    parts8 = torch.full((nparts, P, 3), 9, dtype=torch.uint8, device="cuda")
+    part = torch.zeros((P, 3), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for p in range(nparts):
+        s.render_tiles_dev(cam, opts, rect, ts, p, nparts, part.data_ptr(), None, None)
+        api.rgb_to_ppm8_dev(part.data_ptr(), P, parts8[p].data_ptr(), None)
+        torch.cuda.synchronize()
+    out = torch.full((H, W, 3), 1, dtype=torch.uint8, device="cuda")
+    api.tiles_assemble_bytes_dev(parts8.data_ptr(), nparts, P, rect, ts, 3, out.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert torch.equal(out, want), (W, H, ts, nparts)
+    assert int(want.max()) > 100
+    s.close()
+
+
+WORKER = r"""
+import json, os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, {root!r})
+sys.path.insert(0, os.path.join({root!r}, "tests"))
+from conftest import load_scene_fixture, rtx_materials
+from raytracing_project_amd import api, tiles
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+fx = load_scene_fixture("spheres")
+s = api.Scene(fx["verts"], fx["idx"], fx["tri_mat"], rtx_materials(fx["mats"]))
+s.set_lights([[-1.0, 1.0, 1.0], [1.0, 2.0, 0.5]])
+s.commit(0)
+W, H, TS, NF = 150, 83, 32, 3
+rect = (0, 0, W, H)
+opts = api.Options(2, 1, 0, 0, 1, 0)
+cams = [api.make_camera(fx[v], W, H) for v in ("view_oblique", "view_default", "view_top")]
+kmax = tiles.max_local_tiles(W, H, TS, world)
+P = kmax * TS * TS
+rgb = torch.zeros((NF * P, 3), dtype=torch.float32, device="cuda")
+torch.cuda.synchronize()
+# the rank's tiles of NF frames in one call (what bench.py's ranks do), then the P3 bytes of the same pixels
+s.render_tiles_batch_dev(cams, opts, rect, TS, rank, world, rgb.data_ptr(), None, None)
+rgb8 = torch.zeros((NF * P, 3), dtype=torch.uint8, device="cuda")
+api.rgb_to_ppm8_dev(rgb.data_ptr(), NF * P, rgb8.data_ptr(), torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+g32 = tiles.gather_to_root(rgb.cpu(), world, rank, dist)
+g8 = tiles.gather_to_root(rgb8.cpu(), world, rank, dist)
+ok = {{}}
+if rank == 0:
+    g32, g8 = g32.cuda(), g8.cuda()
+    for f, cam in enumerate(cams):
+        full = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        s.render_dev(cam, opts, rect, full.data_ptr(), None, None)
+        full8 = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+        api.rgb_to_ppm8_dev(full.data_ptr(), W * H, full8.data_ptr(), None)
+        img = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        img8 = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+        api.tiles_assemble_dev(g32.data_ptr() + f * P * 12, world, NF * P, rect, TS, 3, img.data_ptr(), None)
+        api.tiles_assemble_bytes_dev(g8.data_ptr() + f * P * 3, world, NF * P, rect, TS, 3, img8.data_ptr(), None)
+        torch.cuda.synchronize()
+        ok["f32_%d" % f] = bool(torch.equal(img.view(torch.int32), full.view(torch.int32)))
+        ok["rgb8_%d" % f] = bool(torch.equal(img8, full8))
+        ok["lit_%d" % f] = int(full8.max())
+    json.dump(ok, open({out!r}, "w"))
+dist.barrier()
+dist.destroy_process_group()
+s.close()
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_ranks_gather_product_pixels_over_gloo(tmp_path, world):
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    out = str(tmp_path / "ok.json")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, out=out))
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    try:
+        for p in procs:
+            logs.append(p.communicate(timeout=240)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode == 0 for p in procs), "\n".join(x[-1500:] for x in logs)
+    ok = json.load(open(out))
+    for f in range(3):
+        assert ok["f32_%d" % f] is True and ok["rgb8_%d" % f] is True, ok
+        assert ok["lit_%d" % f] > 100

@@ -1,4 +1,5 @@
-"""rtx_trace_closest_noalloc (the entry point that allocates nothing) against rtx_trace_closest_dev.
+"""rtx_trace_closest_noalloc (the entry point that allocates nothing) against rtx_trace_closest_dev -- and, on the
+second (smaller) call, against the CPU oracle's brute force over every triangle (the reference's own algorithm).
 
 Collected last on purpose (file name): the round's end runs pytest -x.  Two calls in a row, the second with a
 smaller input, so that what the first call left in the library's fixed scratch array (ray records, hit
@@ -46,6 +47,13 @@ def test_no_alloc_entry_point_matches_trace_closest_dev():
         assert (f_a >= 0).sum() > len(f_a) // 4
         assert np.array_equal(f_a, f_b)
         assert np.array_equal(t_a.view(np.uint32), t_b.view(np.uint32))
+    # the second call's answers against the oracle: Flyscene::getIntersections restated, every triangle per ray
+    from oracle import oracle_api as oa
+    oa.build()
+    osc = oa.Scene(verts, idx, None, [oa.make_mtl()])
+    h = osc.closest(o2.cpu().numpy(), d2.cpu().numpy(), threads=8)
+    assert np.array_equal(f_b, h["face"]), "face ids differ from the oracle's brute force"
+    assert np.array_equal(t_b.view(np.uint32), h["t"].view(np.uint32)), "hit distances differ from the oracle's brute force"
     # ... and the forced group-by-group scheduler takes the same scratch layout
     s.set_flags(api.FLAG_SCHED_GROUPS)
     t_a, f_a, t_b, f_b = both(o2, d2)
