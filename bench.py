@@ -150,6 +150,8 @@ def main():
     ap.add_argument("--roofline-stride", type=int, default=16, help="every k-th pixel feeds the byte count")
     ap.add_argument("--no-scaling-proxy", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-frame and verification passes")
+    ap.add_argument("--fast-triangles", action="store_true", help="RTX_FLAG_FAST_TRIANGLES: the watertight Moeller-Trumbore functor instead of the reference's "
+                                                                  "arithmetic (hit ids no longer bit-exact; a measurement mode, never the headline)")
     ap.add_argument("--static-camera", action="store_true", help="every frame from the same camera (rounds 1-2 measured that)")
     ap.add_argument("--out-format", default="rgb8", choices=["rgb8", "f32"],
                     help="what the ranks of an N > 1 run hand to rank 0: the P3 bytes of result.ppm (3 B/pixel) or the float frame (12)")
@@ -196,6 +198,8 @@ def main():
     W, H = wl["W"], wl["H"]
     scene = api.Scene(wl["verts"], wl["idx"], wl["tri_mat"], [api.make_material(**m) for m in wl["mats"]])
     scene.set_lights(wl["lights"])
+    if args.fast_triangles:
+        scene.set_flags(api.FLAG_FAST_TRIANGLES)
     scene.commit(local_rank)
     info = scene.info()
     opts = api.Options(*wl["opts"])
@@ -444,11 +448,11 @@ def main():
                   "note": "one frame per render call, one call at a time (host wait included): the latency of a single raytraceScene"}
         # The timed configuration once more with the standing check on: every camera launch re-checks ~2,000 of its rays by
         # brute force over every triangle (the reference's own algorithm); a mismatch would be a hit the hierarchy lost.
-        scene.set_flags(api.FLAG_VERIFY)
+        scene.set_flags(api.FLAG_VERIFY | (api.FLAG_FAST_TRIANGLES if args.fast_triangles else 0))
         cams = [cams_of(f)[0] for f in range(B)]
         scene.render_tiles_batch_dev(cams, opts, rect, 0, 0, 1, sets[0]["rgb"].data_ptr(), None, sets[0]["face"].data_ptr())
         st = scene.stats()
-        scene.set_flags(0)
+        scene.set_flags(api.FLAG_FAST_TRIANGLES if args.fast_triangles else 0)
         verify = {"checked": int(st.verify_checked), "mismatches": int(st.verify_mismatches), "rays_out_of_domain": int(st.rays_out_of_domain),
                   "note": "RTX_FLAG_VERIFY on one batch of %d frames: sampled camera rays re-traced by brute force over all triangles" % B}
     # pixels whose primary ray hit geometry, from the hit ids of the last frame on every rank
@@ -475,6 +479,8 @@ def main():
                        "image": [W, H], "lights": len(wl["lights"]), "spp": wl["spp"], "max_bounces": wl["opts"][0],
                        "camera": "one fixed view" if args.static_camera else "a camera path: every frame from the next position of an orbit about the scene (%.2f degrees per frame)"
                                  % (wl["path"][2] if len(wl.get("path", ())) > 2 else 0.25),
+                       "triangle_test": "watertight Moeller-Trumbore (RTX_FLAG_FAST_TRIANGLES): NOT the reference's arithmetic" if args.fast_triangles
+                                        else "the reference's plane + barycentric arithmetic (bit-exact hit ids)",
                        "tile": TILE, "partition": (("image tiles round-robin over %d ranks, scene replicated, %s gathered to rank 0" % (world, "P3 bytes (rtx_rgb_to_ppm8_dev)" if rgb8 else "float RGB")) if world > 1
                                      else "one rank renders the whole frame row-major") + (("; %d frames per render call (rtx_render_tiles_batch_dev_enqueue), %d calls in flight" % (B, args.inflight)) if pipelined
                                         else "; %d passes per frame (one per sub-pixel sample), %d in flight, summed in pass order" % (len(offsets), args.inflight)),

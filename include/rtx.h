@@ -131,6 +131,15 @@ int rtx_scene_set_lights(rtx_scene*, const float* xyz, uint32_t n, const float* 
  * check of "the BVH only skips triangles the ray cannot hit" on the caller's own scenes, at ~ntris x 2,000 triangle
  * tests per launch.  No counterpart in the reference (which always scans every triangle). */
 #define RTX_FLAG_VERIFY 16u
+/* RTX_FLAG_FAST_TRIANGLES (takes effect at the next rtx_scene_commit): the traversal kernels test triangles with a
+ * watertight Moeller-Trumbore functor (48-byte {v0, e1, e2, face} records, edge functions compared before the one
+ * reciprocal, edges inclusive with a 1e-6 overlap so that neighbouring triangles leave no gap) instead of the
+ * reference's plane + barycentric arithmetic (src/Intersect.cpp:6-46).  Acceptance rules stay the reference's
+ * (t >= 0.001f, lowest face id on equal t, spheres first), but t differs by ulps and a hit within ~1e-6 of an edge may
+ * go to the neighbouring face: hit ids are then NOT bit-exact (DESIGN.md 3 has the measured match rates per scene).
+ * Off by default: the default path is the reference's arithmetic.  With RTX_FLAG_VERIFY the sampled re-check (always
+ * in the reference's arithmetic) counts those differences in rtx_stats.verify_mismatches. */
+#define RTX_FLAG_FAST_TRIANGLES 32u
 int rtx_scene_set_flags(rtx_scene*, uint32_t flags);
 
 /* Flyscene::divideBox_KD + averagePoint / axisToDivide / isInBox and Box(mesh)

@@ -96,7 +96,7 @@ struct rtx_scene {
   int device = -1;
   BvhBuildResult bvh;
   DevScene dev{};
-  DevBuf d_nodes, d_tris, d_tri_face, d_face_nm, d_spheres, d_sph_mat, d_mats, d_lights;
+  DevBuf d_nodes, d_tris, d_tris_mt, d_tri_face, d_face_nm, d_spheres, d_sph_mat, d_mats, d_lights;
   DevBuf d_slights, d_leafboxes, d_leaf_faces, d_face_pos;
   // Workspace of one call: its streams and every buffer its kernels write.  Two of them (one per call slot,
   // below), so that two render calls can be in flight on the GPU at the same time: frame k+1's launches fill the
@@ -199,7 +199,7 @@ extern "C" int rtx_scene_create(const float* verts, uint32_t nverts, const uint3
 
 static void release_device(rtx_scene* s) {
   if (s->device >= 0) (void)hipSetDevice(s->device);
-  DevBuf* bufs[] = {&s->d_nodes, &s->d_tris, &s->d_tri_face, &s->d_face_nm, &s->d_spheres, &s->d_sph_mat, &s->d_mats,
+  DevBuf* bufs[] = {&s->d_nodes, &s->d_tris, &s->d_tris_mt, &s->d_tri_face, &s->d_face_nm, &s->d_spheres, &s->d_sph_mat, &s->d_mats,
                     &s->d_lights, &s->d_slights, &s->d_leafboxes, &s->d_leaf_faces, &s->d_face_pos};
   for (rtx_scene::Slot& w : s->slots) {                        // calls still in flight
     if (w.stream) (void)hipStreamSynchronize(w.stream);
@@ -249,10 +249,11 @@ extern "C" int rtx_scene_set_spheres(rtx_scene* s, const float* cr4, const int32
 
 extern "C" int rtx_scene_set_flags(rtx_scene* s, uint32_t flags) {
   if (!s) return fail(RTX_EINVAL, "null scene");
-  if (flags & ~(uint32_t)(RTX_FLAG_NO_ROOT_GATE | RTX_FLAG_SCHED_REFILL | RTX_FLAG_SCHED_GROUPS | RTX_FLAG_SCHED_SPLIT | RTX_FLAG_VERIFY)) return fail(RTX_EINVAL, "unknown flag bits 0x%x", flags);
+  if (flags & ~(uint32_t)(RTX_FLAG_NO_ROOT_GATE | RTX_FLAG_SCHED_REFILL | RTX_FLAG_SCHED_GROUPS | RTX_FLAG_SCHED_SPLIT | RTX_FLAG_VERIFY | RTX_FLAG_FAST_TRIANGLES))
+    return fail(RTX_EINVAL, "unknown flag bits 0x%x", flags);
   if ((flags & RTX_FLAG_SCHED_REFILL) && (flags & RTX_FLAG_SCHED_GROUPS)) return fail(RTX_EINVAL, "pick one scheduler");
   if ((flags & RTX_FLAG_SCHED_SPLIT) && !(flags & RTX_FLAG_SCHED_REFILL)) return fail(RTX_EINVAL, "RTX_FLAG_SCHED_SPLIT modifies RTX_FLAG_SCHED_REFILL");
-  if ((flags ^ s->flags) & RTX_FLAG_NO_ROOT_GATE) s->committed = false;   // the scheduler bits are host-side only
+  if ((flags ^ s->flags) & (RTX_FLAG_NO_ROOT_GATE | RTX_FLAG_FAST_TRIANGLES)) s->committed = false;   // the scheduler bits are host-side only
   s->flags = flags;
   return RTX_OK;
 }
@@ -563,6 +564,21 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
     }
     if (int rc = upload(s->d_tris, dtris, ws(s).stream)) return rc;
   }
+  // RTX_FLAG_FAST_TRIANGLES: the 48-byte Moeller-Trumbore records {v0, e1.x} {e1.yz, e2.xy} {e2.z, face id, 0, 0}, leaf order
+  // (beside the reference records, which the brute-force guard / verification, the GI probes and the debug ray keep using)
+  if (s->flags & RTX_FLAG_FAST_TRIANGLES) {
+    std::vector<float4> mt((size_t)ntris * 3);
+    for (uint32_t k = 0; k < ntris; ++k) {
+      const float4 a = tri_leaf[4 * (size_t)k], u = tri_leaf[4 * (size_t)k + 1], v = tri_leaf[4 * (size_t)k + 2];
+      float fw; const int32_t f = tri_face[k]; std::memcpy(&fw, &f, 4);
+      mt[3 * (size_t)k] = make_float4(a.x, a.y, a.z, u.x);
+      mt[3 * (size_t)k + 1] = make_float4(u.y, u.z, v.x, v.y);
+      mt[3 * (size_t)k + 2] = make_float4(v.z, fw, 0.0f, 0.0f);
+    }
+    if (int rc = upload(s->d_tris_mt, mt, ws(s).stream)) return rc;
+  } else {
+    s->d_tris_mt.release();
+  }
   if (int rc = upload(s->d_tri_face, tri_face, ws(s).stream)) return rc;
   if (int rc = upload(s->d_face_nm, face_nm, ws(s).stream)) return rc;
   if (int rc = upload(s->d_spheres, ds, ws(s).stream)) return rc;
@@ -588,7 +604,7 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   HIP_TRY(hipStreamSynchronize(ws(s).stream));
 
   DevScene& d = s->dev;
-  d.nodes = s->d_nodes.as<uint4>(); d.tris = s->d_tris.as<float4>(); d.tri_face = s->d_tri_face.as<int>();
+  d.nodes = s->d_nodes.as<uint4>(); d.tris = s->d_tris.as<float4>(); d.tris_mt = s->d_tris_mt.as<float4>(); d.tri_face = s->d_tri_face.as<int>();
   d.face_nm = s->d_face_nm.as<float4>(); d.spheres = s->d_spheres.as<float4>(); d.sph_mat = s->d_sph_mat.as<int>();
   d.mats = s->d_mats.as<DevMat>(); d.lights = s->d_lights.as<float4>();
   d.slights = s->d_slights.as<float4>(); d.leafboxes = s->d_leafboxes.as<float4>();
@@ -634,7 +650,7 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   d.root_entry = 0;     // group 0 holds the children of the root
   rtx_scene_info& in = s->info;
   in.nspheres = d.nspheres; in.nlights = d.nlights; in.nmaterials = d.nmats;
-  in.device_bytes = s->d_nodes.cap + s->d_tris.cap + s->d_tri_face.cap + s->d_face_nm.cap + s->d_spheres.cap +
+  in.device_bytes = s->d_nodes.cap + s->d_tris.cap + s->d_tris_mt.cap + s->d_tri_face.cap + s->d_face_nm.cap + s->d_spheres.cap +
                     s->d_sph_mat.cap + s->d_mats.cap + s->d_lights.cap + s->d_slights.cap + s->d_leafboxes.cap +
                     s->d_leaf_faces.cap + s->d_face_pos.cap;
   for (auto& per_kind : s->tune) for (rtx_scene::Tune& T : per_kind) T = rtx_scene::Tune();     // another scene on this handle: the tuner starts over
@@ -960,12 +976,16 @@ static int launch_trace_camera(rtx_scene* s, const DevCamera& C, uint32_t tiles,
   const uint32_t grid = trace_blocks(s, tiles);
   const uint32_t grid_r = std::min<uint32_t>(grid, (uint32_t)s->ncu * RTX_BLOCKS_REFILL);
   const int mode = sched_pick(s, KIND_CAMERA, (uint64_t)tiles * kBlock);
-  if (mode != SCHED_GROUPS)
-    hipLaunchKernelGGL(k_trace_camera<true>, dim3(grid_r), dim3(kBlock), 0, ws(s).stream, s->dev, C, tiles, grab_size(),
-                       mode == SCHED_REFILL_SPLIT ? kTriMinSplit : 1u, ws(s).w_stack_ovf.as<uint32_t>(), hits);
-  else
-    hipLaunchKernelGGL(k_trace_camera<false>, dim3(grid), dim3(kBlock), 0, ws(s).stream, s->dev, C, tiles, grab_size(), 1u,
-                       ws(s).w_stack_ovf.as<uint32_t>(), hits);
+  const bool fast = (s->flags & RTX_FLAG_FAST_TRIANGLES) != 0;
+  const uint32_t tri_min = mode == SCHED_REFILL_SPLIT ? kTriMinSplit : 1u;
+  uint32_t* ovf = ws(s).w_stack_ovf.as<uint32_t>();
+  if (mode != SCHED_GROUPS) {
+    if (fast) hipLaunchKernelGGL((k_trace_camera<true, FastTri>), dim3(grid_r), dim3(kBlock), 0, ws(s).stream, s->dev, C, tiles, grab_size(), tri_min, ovf, hits);
+    else hipLaunchKernelGGL((k_trace_camera<true, RefTri>), dim3(grid_r), dim3(kBlock), 0, ws(s).stream, s->dev, C, tiles, grab_size(), tri_min, ovf, hits);
+  } else {
+    if (fast) hipLaunchKernelGGL((k_trace_camera<false, FastTri>), dim3(grid), dim3(kBlock), 0, ws(s).stream, s->dev, C, tiles, grab_size(), 1u, ovf, hits);
+    else hipLaunchKernelGGL((k_trace_camera<false, RefTri>), dim3(grid), dim3(kBlock), 0, ws(s).stream, s->dev, C, tiles, grab_size(), 1u, ovf, hits);
+  }
   return RTX_OK;
 }
 static int launch_trace_queue(rtx_scene* s, const float4* rays, const uint32_t* count, uint32_t stride, uint64_t bound, uint2* hits,
@@ -976,12 +996,15 @@ static int launch_trace_queue(rtx_scene* s, const float4* rays, const uint32_t* 
   const uint32_t grid_r = std::min<uint32_t>(grid, (uint32_t)s->ncu * RTX_BLOCKS_REFILL);
   const int mode = sched_pick(s, shadow ? KIND_SHADOW : KIND_BOUNCE, bound * stride);
   const uint32_t bounded = shadow ? ((any_blocker ? 3u : 1u) | 4u) : 0u;      // 4: the queue is in shadow_index order
-  if (mode != SCHED_GROUPS)
-    hipLaunchKernelGGL(k_trace_queue<true>, dim3(grid_r), dim3(kBlock), 0, on, s->dev, rays, count, stride, bounded, grab_size(),
-                       mode == SCHED_REFILL_SPLIT ? kTriMinSplit : 1u, ovf, hits);
-  else
-    hipLaunchKernelGGL(k_trace_queue<false>, dim3(grid), dim3(kBlock), 0, on, s->dev, rays, count, stride, bounded, grab_size(), 1u,
-                       ovf, hits);
+  const bool fast = (s->flags & RTX_FLAG_FAST_TRIANGLES) != 0;
+  const uint32_t tri_min = mode == SCHED_REFILL_SPLIT ? kTriMinSplit : 1u;
+  if (mode != SCHED_GROUPS) {
+    if (fast) hipLaunchKernelGGL((k_trace_queue<true, FastTri>), dim3(grid_r), dim3(kBlock), 0, on, s->dev, rays, count, stride, bounded, grab_size(), tri_min, ovf, hits);
+    else hipLaunchKernelGGL((k_trace_queue<true, RefTri>), dim3(grid_r), dim3(kBlock), 0, on, s->dev, rays, count, stride, bounded, grab_size(), tri_min, ovf, hits);
+  } else {
+    if (fast) hipLaunchKernelGGL((k_trace_queue<false, FastTri>), dim3(grid), dim3(kBlock), 0, on, s->dev, rays, count, stride, bounded, grab_size(), 1u, ovf, hits);
+    else hipLaunchKernelGGL((k_trace_queue<false, RefTri>), dim3(grid), dim3(kBlock), 0, on, s->dev, rays, count, stride, bounded, grab_size(), 1u, ovf, hits);
+  }
   return RTX_OK;
 }
 
@@ -1860,11 +1883,15 @@ extern "C" int rtx_trace_closest_noalloc(rtx_scene* s, const float* o, const flo
   hipLaunchKernelGGL(k_make_rays, dim3(blocks), dim3(256), 0, st, o, d, n, rays);
   const uint32_t grid = std::min<uint32_t>(blocks, kNoAllocBlocks);
   // the scheduler: what the scene's flags force, else the heuristic's pick for queued rays (no tuner trial here)
-  if (s->flags & RTX_FLAG_SCHED_GROUPS)
-    hipLaunchKernelGGL(k_trace_queue<false>, dim3(grid), dim3(kBlock), 0, st, s->dev, rays, count, 1u, 0u, grab_size(), 1u, ovf, hits);
-  else
-    hipLaunchKernelGGL(k_trace_queue<true>, dim3(grid), dim3(kBlock), 0, st, s->dev, rays, count, 1u, 0u, grab_size(),
-                       (s->flags & RTX_FLAG_SCHED_SPLIT) ? kTriMinSplit : 1u, ovf, hits);
+  const bool fast = (s->flags & RTX_FLAG_FAST_TRIANGLES) != 0;
+  const uint32_t tri_min = (s->flags & RTX_FLAG_SCHED_SPLIT) ? kTriMinSplit : 1u;
+  if (s->flags & RTX_FLAG_SCHED_GROUPS) {
+    if (fast) hipLaunchKernelGGL((k_trace_queue<false, FastTri>), dim3(grid), dim3(kBlock), 0, st, s->dev, rays, count, 1u, 0u, grab_size(), 1u, ovf, hits);
+    else hipLaunchKernelGGL((k_trace_queue<false, RefTri>), dim3(grid), dim3(kBlock), 0, st, s->dev, rays, count, 1u, 0u, grab_size(), 1u, ovf, hits);
+  } else {
+    if (fast) hipLaunchKernelGGL((k_trace_queue<true, FastTri>), dim3(grid), dim3(kBlock), 0, st, s->dev, rays, count, 1u, 0u, grab_size(), tri_min, ovf, hits);
+    else hipLaunchKernelGGL((k_trace_queue<true, RefTri>), dim3(grid), dim3(kBlock), 0, st, s->dev, rays, count, 1u, 0u, grab_size(), tri_min, ovf, hits);
+  }
   // the domain guard as in rtx_trace_closest_dev (its counters, never read back, live in the scratch array too)
   if (s->dev.ntris != 0 || s->dev.nspheres != 0)
     hipLaunchKernelGGL(k_guard_queue, dim3(std::min<uint32_t>(n, kNoAllocBlocks * 8u)), dim3(kBlock), 0, st, s->dev, (const float4*)rays, (const uint32_t*)count, 1u, 0u,

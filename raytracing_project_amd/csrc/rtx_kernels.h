@@ -71,6 +71,7 @@ static_assert(sizeof(DevMat) == 64, "material record is 64 bytes");
 struct DevScene {
   const uint4* nodes;      // 4 x uint4 per 64-byte packed group of 4 sibling nodes (PackedGroup, bvh_build.h)
   const float4* tris;      // 4 x float4 per leaf-ordered triangle: {n,D} {v0,vv} {u,uu} {v,uv}
+  const float4* tris_mt;   // RTX_FLAG_FAST_TRIANGLES only: 3 x float4 per leaf-ordered triangle, {v0, e1.x} {e1.yz, e2.xy} {e2.z, face id, -, -}
   const int* tri_face;     // leaf order -> mesh face id
   const float4* face_nm;   // per mesh face: {query normal xyz, material id bits}
   const float4* spheres;   // {center xyz, radius}
@@ -213,6 +214,43 @@ __device__ __forceinline__ void test_triangle(const DevScene& S, uint32_t k, V3 
     if (t < best->t || (t == best->t && face < best->id)) { best->t = t; best->id = face; }
   }
 }
+
+// The triangle test of the traversal kernels is a functor, so that the default path stays exactly the code above.
+struct RefTri {
+  static __device__ __forceinline__ void test(const DevScene& S, uint32_t k, V3 o, V3 d, Hit* best) { test_triangle(S, k, o, d, best); }
+};
+// Opt-in (RTX_FLAG_FAST_TRIANGLES): Moeller-Trumbore over a 48-byte {v0, e1, e2, face} record, made watertight by
+// overlap -- the edge functions U, V, det - U - V are compared before any division, edges inclusive, with a tolerance
+// of 1e-6 |det|, so that neighbouring triangles overlap by a millionth of their size rather than leave a gap (a double
+// hit is harmless to a closest-hit search).  One reciprocal instead of the reference's three divisions, fused
+// multiply-adds, three loads of which none depends on a comparison, the face id in the record.  Same acceptance rules
+// as the reference: t >= 0.001f, (t, face) lexicographic minimum, a NaN anywhere rejects.  NOT the reference's
+// arithmetic: t differs by ulps and hits within ~1e-6 of an edge may go to the neighbour (DESIGN.md 3 has the measured
+// id-match rates).
+struct FastTri {
+  static __device__ __forceinline__ void test(const DevScene& S, uint32_t k, V3 o, V3 d, Hit* best) {
+    const float4 a = S.tris_mt[3 * k], b = S.tris_mt[3 * k + 1], c = S.tris_mt[3 * k + 2];
+    const V3 e1 = v3(a.w, b.x, b.y), e2 = v3(b.z, b.w, c.x);
+    const V3 tv = v3(o.x - a.x, o.y - a.y, o.z - a.z);
+    // p = d x e2, q = tv x e1
+    const float px = __builtin_fmaf(d.y, e2.z, -(d.z * e2.y)), py = __builtin_fmaf(d.z, e2.x, -(d.x * e2.z)), pz = __builtin_fmaf(d.x, e2.y, -(d.y * e2.x));
+    const float det = __builtin_fmaf(e1.x, px, __builtin_fmaf(e1.y, py, e1.z * pz));
+    const float U = __builtin_fmaf(tv.x, px, __builtin_fmaf(tv.y, py, tv.z * pz));
+    const float qx = __builtin_fmaf(tv.y, e1.z, -(tv.z * e1.y)), qy = __builtin_fmaf(tv.z, e1.x, -(tv.x * e1.z)), qz = __builtin_fmaf(tv.x, e1.y, -(tv.y * e1.x));
+    const float V = __builtin_fmaf(d.x, qx, __builtin_fmaf(d.y, qy, d.z * qz));
+    const float T = __builtin_fmaf(e2.x, qx, __builtin_fmaf(e2.y, qy, e2.z * qz));
+    // everything times sign(det): the tests below are those of a front-facing triangle
+    const uint32_t sg = __float_as_uint(det) & 0x80000000u;
+    const float ad = fabsf(det);
+    const float Us = __uint_as_float(__float_as_uint(U) ^ sg), Vs = __uint_as_float(__float_as_uint(V) ^ sg), Ts = __uint_as_float(__float_as_uint(T) ^ sg);
+    const float tol = 1e-6f * ad;
+    if (!(ad > 0.0f && Us >= -tol && Vs >= -tol && Us + Vs <= ad + tol && Ts > 0.0f)) return;
+    const float t = Ts * __builtin_amdgcn_rcpf(ad);
+    if (!(t >= kPrecision && t <= best->t)) return;
+    const int face = __float_as_int(c.y);
+    if (t < best->t || (t == best->t && face < best->id)) { best->t = t; best->id = face; }
+  }
+};
 
 // Per-lane traversal stack: entries [0, kLdsStack) in LDS (column of this thread, stride
 // kBlock, so lane <-> bank and no conflicts), entries beyond in global memory (column of this
@@ -540,7 +578,7 @@ constexpr int kDeferMin = RTX_DEFER_MIN;
 constexpr int kBlockMin = RTX_BLOCK_MIN;
 constexpr int kWbufWords = 9;             // o.xyz, d.xyz, best.t, best.id, slot
 
-template <class Source>
+template <class Tri, class Source>
 __device__ __forceinline__ void trace_wave(const DevScene& S, const TopLevels<kTopGroupsRefill>& top, const Source& src, Work work, const Stack<kLdsStack>& stk, lds_u32* wbuf,
                                            uint32_t tri_min, uint2* hits) {
   const uint32_t lane = threadIdx.x & 63;
@@ -583,7 +621,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& S, const TopLevels<kT
             // intersectBox / intersectTriangle rebuild the Ray, re-normalising d1 (src/flyscene.cpp:845,965)
             sd = normalized(sd1);
             if ((S.flags & 1u) || ref_box_t(so, sd, S.root_lo, S.root_hi) != INFINITY) {
-              for (uint32_t k = S.ntris - S.nwild; k < S.ntris; ++k) test_triangle(S, k, so, sd, &sb);
+              for (uint32_t k = S.ntris - S.nwild; k < S.ntris; ++k) Tri::test(S, k, so, sd, &sb);
               park = S.nwild != S.ntris && ray_is_finite(so, sd);
             }
           }
@@ -658,7 +696,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& S, const TopLevels<kT
       const uint32_t leaf = has_pend ? pend : cur;
       uint32_t first = leaf & 0x0FFFFFFFu, cnt = want_leaf ? (leaf >> 28) & 7u : 0u;
       do {
-        if (cnt != 0) { test_triangle(S, first, o, d, &best); ++first; --cnt; }
+        if (cnt != 0) { Tri::test(S, first, o, d, &best); ++first; --cnt; }
       } while ((uint32_t)__popcll(__ballot(cnt != 0)) >= tri_min);
       if (want_leaf) {
         const uint32_t rest = cnt != 0 ? (0x80000000u | (cnt << 28) | first) : kDone;
@@ -680,7 +718,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& S, const TopLevels<kT
 // bookkeeping per step, which wins where the rays of a group stay in step (coherent rays on
 // closed surfaces); the refilling scheduler above wins on incoherent work (triangle soups,
 // diffuse bounces).
-template <class Source>
+template <class Tri, class Source>
 __device__ __forceinline__ void trace_wave_groups(const DevScene& S, const TopLevels<kTopGroups>& top, const Source& src, Work work, const Stack<kLdsStackGroups>& stk,
                                                   uint2* hits) {
   const uint32_t lane = threadIdx.x & 63;
@@ -700,7 +738,7 @@ __device__ __forceinline__ void trace_wave_groups(const DevScene& S, const TopLe
       if (S.ntris != 0) {
         d = normalized(d1);
         if ((S.flags & 1u) || ref_box_t(o, d, S.root_lo, S.root_hi) != INFINITY) {
-          for (uint32_t k = S.ntris - S.nwild; k < S.ntris; ++k) test_triangle(S, k, o, d, &best);
+          for (uint32_t k = S.ntris - S.nwild; k < S.ntris; ++k) Tri::test(S, k, o, d, &best);
           walk = S.nwild != S.ntris && ray_is_finite(o, d);
         }
       }
@@ -715,7 +753,7 @@ __device__ __forceinline__ void trace_wave_groups(const DevScene& S, const TopLe
             if (node_step(S, top, stk, best.t * kPruneSlack, ivx, ivy, ivz, oix, oiy, oiz, &cur, &sp)) continue;
           } else {
             const uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
-            for (uint32_t k = first; k < first + cnt; ++k) test_triangle(S, k, o, d, &best);
+            for (uint32_t k = first; k < first + cnt; ++k) Tri::test(S, k, o, d, &best);
             if (src.first_hit_decides() && best.id != -1 && best.t < 0.998f * src.tmax_of(slot)) break;
           }
           if (sp == 0) break;
@@ -814,7 +852,7 @@ __global__ __launch_bounds__(kBlock) void k_guard_queue(DevScene S, const float4
 
 // Camera rays of a pixel rectangle.  Ray index j = (16x16 pixel block, thread): consecutive
 // indices walk 8x8 pixel sub-tiles, so the 64 rays of a chunk are coherent.  Writes {t, id}.
-template <bool kRefill>
+template <bool kRefill, class Tri = RefTri>
 __global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_trace_camera(DevScene S, DevCamera C, uint32_t nblocks, uint32_t grab, uint32_t tri_min, uint32_t* ovf,
                                                           uint2* hits) {
   __shared__ uint32_t lds_stack[(kRefill ? kLdsStack : kLdsStackGroups) * kBlock];
@@ -826,14 +864,14 @@ __global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_tra
   const Work work = make_work(nblocks * (uint32_t)kBlock, grab, &lds_ctr);
   if constexpr (kRefill) {
     __shared__ uint32_t lds_wbuf[(kBlock / 64) * kWbufWords * 64];
-    trace_wave(S, top, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), tri_min, hits);
+    trace_wave<Tri>(S, top, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), tri_min, hits);
   } else {
-    trace_wave_groups(S, top, src, work, make_stack<kLdsStackGroups>(lds_stack, ovf), hits);
+    trace_wave_groups<Tri>(S, top, src, work, make_stack<kLdsStackGroups>(lds_stack, ovf), hits);
   }
 }
 
 // Queued rays: rays[2i] = {o.xyz, aux}, rays[2i+1] = {d1.xyz, aux}; *count * stride rays.
-template <bool kRefill>
+template <bool kRefill, class Tri = RefTri>
 __global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_trace_queue(DevScene S, const float4* rays, const uint32_t* count, uint32_t stride,
                                                          uint32_t bounded, uint32_t grab, uint32_t tri_min, uint32_t* ovf, uint2* hits) {
   __shared__ uint32_t lds_stack[(kRefill ? kLdsStack : kLdsStackGroups) * kBlock];
@@ -848,9 +886,9 @@ __global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_tra
   const Work work = make_work(n, grab, &lds_ctr);
   if constexpr (kRefill) {
     __shared__ uint32_t lds_wbuf[(kBlock / 64) * kWbufWords * 64];
-    trace_wave(S, top, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), tri_min, hits);
+    trace_wave<Tri>(S, top, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), tri_min, hits);
   } else {
-    trace_wave_groups(S, top, src, work, make_stack<kLdsStackGroups>(lds_stack, ovf), hits);
+    trace_wave_groups<Tri>(S, top, src, work, make_stack<kLdsStackGroups>(lds_stack, ovf), hits);
   }
 }
 

@@ -3,7 +3,7 @@
 TAG=$1; shift
 mkdir -p gpurun_out
 for wl in soup1M_4k_primary_shadow bunny70k_1080p_primary_shadow hall262k_1080p_reflect3; do
-  timeout -k 10 300 python3 -u bench.py --steps 32 --warmup 8 --no-scaling-proxy --no-cpu-baseline --no-roofline --workload $wl "$@" > gpurun_out/qb_${TAG}_$wl.log 2>&1 || { echo "$wl failed"; tail -5 gpurun_out/qb_${TAG}_$wl.log; exit 1; }
+  timeout -k 10 300 python3 -u bench.py --steps 32 --warmup 8 --no-scaling-proxy --no-cpu-baseline --no-roofline --no-extras --repeats 3 --workload $wl "$@" > gpurun_out/qb_${TAG}_$wl.log 2>&1 || { echo "$wl failed"; tail -5 gpurun_out/qb_${TAG}_$wl.log; exit 1; }
   python3 - <<PY
 import json
 l=[x for x in open("gpurun_out/qb_${TAG}_$wl.log") if x.startswith("{")][-1]
