@@ -19,6 +19,7 @@
 #include <chrono>
 #include <fstream>
 #include <iostream>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -448,6 +449,16 @@ inline void writePPMImage(const std::string& filename, const std::vector<std::ve
 }
 
 // ---- Flyscene (src/flyscene.hpp:30-221), ray-tracing half
+//
+// Threading.  The reference calls its queries from 16 std::threads at once (raytraceScene spawns them over
+// updating_pixels, src/flyscene.cpp:417-430) and mutates the scene only between renders (src/main.cpp:63-77).  The C
+// ABI underneath wants the calls on one rtx_scene serialised (include/rtx.h), and this object caches a frame, so every
+// public method takes the object's mutex (recursive: Shader calls getIntersections, the debug ray calls canSeeLight):
+// sixteen threads running the reference's own updating_pixels(pixel_data, origin, size, 16, tid) render ONE frame --
+// the first to arrive launches it, the others find it cached -- and each copies its own rows.  Per-ray queries from
+// many threads are correct but serialised, one GPU round trip each; the vector overloads (getIntersections(rays),
+// traceRay(bounce, rays, inside), canSeeLight(light, positions)) answer a whole batch in one launch and are what a
+// caller with more than a handful of rays should use.
 class Flyscene {
  public:
   std::string model_path = "resources/models/planeobj.obj";     // src/flyscene.cpp:22-23
@@ -463,6 +474,7 @@ class Flyscene {
 
   // src/flyscene.cpp:13-120 without the GL parts
   void initialize(int width, int height) {
+    std::lock_guard<std::recursive_mutex> guard(mu);
     flycamera.setPerspectiveMatrix(60.0f, width / (float)height, 0.1f, 100.0f);
     flycamera.setViewport(Vector2f((float)width, (float)height));
     mesh = MeshData(); materials.clear();
@@ -474,8 +486,8 @@ class Flyscene {
     rebuild();
   }
   Tucano::Flycamera* getCamera() { return &flycamera; }
-  void addLight() { lights.push_back(getCenter()); dirty = true; }                       // src/flyscene.hpp:61
-  void addSphericalLight() { sphericalLights.push_back({getCenter(), 0.01f}); dirty = true; }   // :62
+  void addLight() { std::lock_guard<std::recursive_mutex> guard(mu); lights.push_back(getCenter()); dirty = true; }                       // src/flyscene.hpp:61
+  void addSphericalLight() { std::lock_guard<std::recursive_mutex> guard(mu); sphericalLights.push_back({getCenter(), 0.01f}); dirty = true; }   // :62
   int getNumberOfFaces() const { return (int)mesh.tri_mat.size(); }
 
   // src/flyscene.cpp:395-439.  The frame buffer is indexed [x][y] as the reference does (:465); the
@@ -483,6 +495,7 @@ class Flyscene {
   // otherwise.  Here it is allocated [width][height]: the same object for square frames (result.ppm byte-identical),
   // and a defined result for every other size.
   void raytraceScene(int width = 0, int height = 0) {
+    std::lock_guard<std::recursive_mutex> guard(mu);
     std::cout << "ray tracing ..." << std::endl;
     auto t0 = std::chrono::steady_clock::now();
     Vector2i image_size(width, height);
@@ -509,6 +522,7 @@ class Flyscene {
   // added once, not once per thread.
   void updating_pixels(std::vector<std::vector<Vector3f>>& pixel_data, Vector3f& /*origin*/, Vector2i& image_size,
                        int number_threads, int thread_id) {
+    std::lock_guard<std::recursive_mutex> guard(mu);
     const int W = image_size[0], H = image_size[1];
     if (W <= 0 || H <= 0 || number_threads <= 0 || thread_id < 0) throw RtxError(RTX_EINVAL, "updating_pixels: bad image size or thread index");
     if ((int)pixel_data.size() < W) throw RtxError(RTX_EINVAL, "updating_pixels: pixel_data[x][y] needs image_size[0] columns (SURVEY F8)");
@@ -516,9 +530,10 @@ class Flyscene {
       if ((int)pixel_data[i].size() < H) throw RtxError(RTX_EINVAL, "updating_pixels: pixel_data[x][y] needs image_size[1] entries per column (SURVEY F8)");
     if (!spheres_added) add_reference_spheres();
     sync();
-    if (frame_w != W || frame_h != H || frame_dirty) {
+    rtx_camera cam = flycamera.raw();
+    // (the camera is reachable through getCamera(): a frame cached for another view is not this call's frame)
+    if (frame_w != W || frame_h != H || frame_dirty || std::memcmp(&cam, &frame_cam, sizeof cam) != 0) {
       frame.resize((size_t)W * H * 3);
-      rtx_camera cam = flycamera.raw();
       rtx_rect r{0, 0, W, H};
       int ndev = rtx_device_count();
       int parts = render_parts > 0 ? render_parts : ndev;
@@ -530,7 +545,7 @@ class Flyscene {
       } else {
         rtx_check(rtx_render(scene, &cam, &options, r, frame.data(), nullptr, nullptr));
       }
-      frame_w = W; frame_h = H; frame_dirty = false;
+      frame_w = W; frame_h = H; frame_dirty = false; frame_cam = cam; ++frames_rendered;
     }
     for (int j = thread_id; j < H; j += number_threads)
       for (int i = 0; i < W; ++i) {
@@ -541,6 +556,7 @@ class Flyscene {
 
   // src/flyscene.cpp:587-601
   Vector3f traceRay(int bounce, Ray ray, bool insideObject) {
+    std::lock_guard<std::recursive_mutex> guard(mu);
     sync();
     Vector3f o = ray.getOrigin(), d = ray.getDirection(), c;
     rtx_check(rtx_trace_shade(scene, &options, o.v, d.v, 1, bounce, insideObject ? 1 : 0, c.v));
@@ -551,6 +567,7 @@ class Flyscene {
   // this forwards to traceRay, and refuses a hit that is not the ray's own closest hit (calculateColor, its per-light term,
   // takes intermediate state of that sum and has no entry point of its own: call traceRay / Shader).
   Vector3f Shader(int bounce, Tucano::Face /*face*/, HitInfo hit, Ray ray, bool insideObject) {
+    std::lock_guard<std::recursive_mutex> guard(mu);
     const std::pair<HitInfo, Tucano::Face> own = getIntersections(ray);
     if (own.first.faceId != hit.faceId || std::memcmp(&own.first.t, &hit.t, 4) != 0)
       throw RtxError(RTX_EINVAL, "rtx: Shader() takes the hit getIntersections() returns for the same ray");
@@ -558,6 +575,7 @@ class Flyscene {
   }
   // src/flyscene.cpp:517-585
   std::pair<HitInfo, Tucano::Face> getIntersections(Ray ray) {
+    std::lock_guard<std::recursive_mutex> guard(mu);
     sync();
     Vector3f o = ray.getOrigin(), d = ray.getDirection();
     HitInfo h; int mat = -1;
@@ -571,6 +589,7 @@ class Flyscene {
   // The scene built for a face list is kept until another list (or other vertices) comes: the reference's callers ask
   // ray after ray against the same leaf (src/flyscene.cpp:553-577).
   HitInfo intersectTriangle(std::vector<Tucano::Face>& faces, Vector3f origin, Vector3f dir) {
+    std::lock_guard<std::recursive_mutex> guard(mu);
     std::vector<uint32_t> idx; idx.reserve(faces.size() * 3);
     for (auto& f : faces) for (int k = 0; k < 3; ++k) idx.push_back(f.vertex_ids[k]);
     if (!tri_scene || idx != tri_idx || mesh.verts != tri_verts) {
@@ -589,6 +608,7 @@ class Flyscene {
   }
   // src/flyscene.cpp:906-972
   HitInfo intersectBox(Box& box, Vector3f origin, Vector3f dest) {
+    std::lock_guard<std::recursive_mutex> guard(mu);
     sync();
     HitInfo h{INFINITY, -1, Vector3f(), Vector3f()};
     rtx_check(rtx_intersect_box(scene, box.tmin.v, box.tmax.v, origin.v, dest.v, 1, &h.t));
@@ -596,6 +616,7 @@ class Flyscene {
   }
   // src/flyscene.cpp:747-782
   std::pair<bool, Tucano::Material::Mtl> canSeeLight(Vector3f lightPos, Vector3f position) {
+    std::lock_guard<std::recursive_mutex> guard(mu);
     sync();
     uint8_t vis = 0; int bm = -1;
     rtx_check(rtx_trace_visible(scene, lightPos.v, position.v, 1, &vis, &bm));
@@ -603,8 +624,60 @@ class Flyscene {
     if (bm >= 0 && bm < (int)materials.size()) m = materials[bm];
     return std::make_pair(vis != 0, m);
   }
+  // ---- the same queries for many rays in ONE launch (no counterpart in the reference, whose callers loop; results are
+  // element for element those of the single-ray methods above)
+  std::vector<std::pair<HitInfo, Tucano::Face>> getIntersections(const std::vector<Ray>& rays) {
+    std::lock_guard<std::recursive_mutex> guard(mu);
+    sync();
+    const size_t n = rays.size();
+    std::vector<std::pair<HitInfo, Tucano::Face>> out(n);
+    if (n == 0) return out;
+    std::vector<float> o(3 * n), d(3 * n), t(n), nrm(3 * n), pt(3 * n);
+    std::vector<int32_t> face(n), mat(n);
+    flatten(rays, o, d);
+    rtx_check(rtx_trace_closest(scene, o.data(), d.data(), (uint32_t)n, t.data(), face.data(), nrm.data(), pt.data(), mat.data()));
+    for (size_t i = 0; i < n; ++i) {
+      HitInfo h{t[i], face[i], Vector3f(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]), Vector3f(pt[3 * i], pt[3 * i + 1], pt[3 * i + 2])};
+      Tucano::Face f;
+      if (face[i] >= 0) f = make_face(face[i]);
+      f.material_id = mat[i];
+      out[i] = std::make_pair(h, f);
+    }
+    return out;
+  }
+  std::vector<Vector3f> traceRay(int bounce, const std::vector<Ray>& rays, bool insideObject) {
+    std::lock_guard<std::recursive_mutex> guard(mu);
+    sync();
+    const size_t n = rays.size();
+    std::vector<Vector3f> out(n);
+    if (n == 0) return out;
+    std::vector<float> o(3 * n), d(3 * n), c(3 * n);
+    flatten(rays, o, d);
+    rtx_check(rtx_trace_shade(scene, &options, o.data(), d.data(), (uint32_t)n, bounce, insideObject ? 1 : 0, c.data()));
+    for (size_t i = 0; i < n; ++i) out[i] = Vector3f(c[3 * i], c[3 * i + 1], c[3 * i + 2]);
+    return out;
+  }
+  std::vector<std::pair<bool, Tucano::Material::Mtl>> canSeeLight(Vector3f lightPos, const std::vector<Vector3f>& positions) {
+    std::lock_guard<std::recursive_mutex> guard(mu);
+    sync();
+    const size_t n = positions.size();
+    std::vector<std::pair<bool, Tucano::Material::Mtl>> out(n);
+    if (n == 0) return out;
+    std::vector<float> L(3 * n), P(3 * n);
+    std::vector<uint8_t> vis(n);
+    std::vector<int32_t> bm(n);
+    for (size_t i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) { L[3 * i + k] = lightPos[k]; P[3 * i + k] = positions[i][k]; }
+    rtx_check(rtx_trace_visible(scene, L.data(), P.data(), (uint32_t)n, vis.data(), bm.data()));
+    for (size_t i = 0; i < n; ++i) {
+      Tucano::Material::Mtl m;
+      if (bm[i] >= 0 && bm[i] < (int)materials.size()) m = materials[bm[i]];
+      out[i] = std::make_pair(vis[i] != 0, m);
+    }
+    return out;
+  }
   // src/flyscene.cpp:631-669: (Kd, t) of the closest hit over the spheres and the leaf list `boxes`; zeros on a miss
   Vector4f trace_global_illum(Ray& ray) {
+    std::lock_guard<std::recursive_mutex> guard(mu);
     sync();
     Vector3f o = ray.getOrigin(), d = ray.getDirection();
     Vector4f r;
@@ -615,6 +688,7 @@ class Flyscene {
   // reference either).  Throws where the reference's split would never terminate.
   std::vector<Box> boxes;
   void divideBox_KD(int max_numberFaces) {
+    std::lock_guard<std::recursive_mutex> guard(mu);
     int leaves = rtx_scene_build_reference_leafboxes(scene, max_numberFaces, 0);
     if (leaves < 0) throw RtxError(leaves, std::string("rtx: ") + rtx_last_error());
     dirty = true;
@@ -622,6 +696,7 @@ class Flyscene {
     std::cout << "Number of leafs: " << boxes.size() << std::endl;            // :1184
   }
   Vector3f getCenter() {
+    std::lock_guard<std::recursive_mutex> guard(mu);
     sync();
     rtx_camera cam = flycamera.raw();
     Vector3f c;
@@ -629,6 +704,7 @@ class Flyscene {
     return c;
   }
   Vector3f screenToWorld(const Vector2f& p) {
+    std::lock_guard<std::recursive_mutex> guard(mu);
     sync();
     rtx_camera cam = flycamera.raw();
     Vector3f w;
@@ -645,12 +721,14 @@ class Flyscene {
   std::vector<int> ray_hitbox;
   int jumps = 0;
   void createDebugRay(const Vector2f& mouse_pos) {
+    std::lock_guard<std::recursive_mutex> guard(mu);
     rays.clear(); ray_hitbox.clear(); light_rays.clear();
     Vector3f screen_pos = screenToWorld(mouse_pos);
     Vector3f dir = (screen_pos - getCenter()).normalized();
     ReflectDebugRay(getCenter(), dir, 0, jumps);
   }
   void ReflectDebugRay(Vector3f origin, Vector3f dir, int bounce, int jumps_) {
+    std::lock_guard<std::recursive_mutex> guard(mu);
     sync();
     uint32_t nl = 0, nf = 0;
     rtx_check(rtx_scene_get_leafboxes(scene, nullptr, nullptr, nullptr, nullptr, nullptr, &nl, &nf));
@@ -671,8 +749,9 @@ class Flyscene {
       origin = nr.getOrigin(); dir = nr.getDirection();
     }
   }
-  const rtx_stats& lastStats() { rtx_get_stats(scene, &stats); return stats; }
-  void markCameraChanged() { frame_dirty = true; }
+  rtx_stats lastStats() { std::lock_guard<std::recursive_mutex> guard(mu); rtx_get_stats(scene, &stats); return stats; }
+  void markCameraChanged() { std::lock_guard<std::recursive_mutex> guard(mu); frame_dirty = true; }
+  int framesRendered() { std::lock_guard<std::recursive_mutex> guard(mu); return frames_rendered; }   // GPU frames launched by updating_pixels so far
 
   std::vector<Vector3f> lights;
   std::vector<std::pair<Vector3f, float>> sphericalLights;
@@ -694,6 +773,15 @@ class Flyscene {
       {1.0f, 0.75f, 1.0f}, {0.0f, 0.7f, 1.0f}, {1.0f, 0.5f, 0.3f}, {0.0f, 0.3f, 0.123f}};
 
  private:
+  std::recursive_mutex mu;                   // every public method holds it (see "Threading" above)
+  int frames_rendered = 0;
+  static void flatten(const std::vector<Ray>& rays, std::vector<float>& o, std::vector<float>& d) {
+    for (size_t i = 0; i < rays.size(); ++i) {
+      Ray r = rays[i];
+      const Vector3f ro = r.getOrigin(), rd = r.getDirection();
+      for (int k = 0; k < 3; ++k) { o[3 * i + k] = ro[k]; d[3 * i + k] = rd[k]; }
+    }
+  }
   Tucano::Flycamera flycamera;
   MeshData mesh;
   size_t mesh_materials = 0;
@@ -704,6 +792,7 @@ class Flyscene {
   bool dirty = true, spheres_added = false, frame_dirty = true;
   std::vector<float> frame;
   int frame_w = 0, frame_h = 0;
+  rtx_camera frame_cam{};
   rtx_stats stats{};
 
   std::vector<rtx_scene*> replicas;        // handles 1 .. parts-1 of rtx_render_multi (clones of `scene`, committed on their devices)

@@ -47,6 +47,28 @@ int main(int argc, char** argv) {
         if (!refused) { std::printf("Shader() accepted a hit that is not the ray's\n"); return 1; }
       }
     }
+    // the batched forms of the per-ray queries: one launch for all rays, element for element the single-ray answers
+    {
+      in.clear(); in.seekg(0);
+      std::vector<Ray> many;
+      while (in >> o[0] >> o[1] >> o[2] >> d[0] >> d[1] >> d[2]) many.push_back(Ray(Vector3f(o[0], o[1], o[2]), Vector3f(d[0], d[1], d[2])));
+      auto hs = fs.getIntersections(many);
+      auto cs = fs.traceRay(0, many, false);
+      std::vector<Vector3f> pts;
+      for (auto& h : hs) pts.push_back(h.first.point);
+      auto vs = fs.canSeeLight(fs.lights[0], pts);
+      int bad = 0;
+      for (size_t i = 0; i < many.size(); ++i) {
+        auto h1 = fs.getIntersections(many[i]);
+        Vector3f c1 = fs.traceRay(0, many[i], false);
+        if (std::memcmp(&h1.first.t, &hs[i].first.t, 4) || h1.first.faceId != hs[i].first.faceId || h1.second.material_id != hs[i].second.material_id ||
+            std::memcmp(h1.first.normal.v, hs[i].first.normal.v, 12) || std::memcmp(h1.first.point.v, hs[i].first.point.v, 12) ||
+            h1.second.vertex_ids != hs[i].second.vertex_ids) ++bad;
+        if (std::memcmp(c1.v, cs[i].v, 12)) ++bad;
+        if (h1.first.t != INFINITY && fs.canSeeLight(fs.lights[0], h1.first.point).first != vs[i].first) ++bad;
+      }
+      std::printf("batched %zu %d\n", many.size(), bad);
+    }
     // the primitive classes and the GI probe by name (src/Intersect.h:8-89, src/flyscene.cpp:631-669), first rays again
     std::printf("boxes %zu", fs.boxes.size());
     for (auto& b : fs.boxes) std::printf(" %zu", b.triangles.size());
@@ -88,6 +110,15 @@ int main(int argc, char** argv) {
     std::printf("frame rays %llu %llu %llu %llu %llu\n", (unsigned long long)st.rays_primary, (unsigned long long)st.rays_shadow,
                 (unsigned long long)st.rays_reflection, (unsigned long long)st.rays_refraction, (unsigned long long)st.rays_gi);
     std::rename("result.ppm", "result_square.ppm");
+    {   // the float frame behind that file (the cached frame again, through the reference's own call), row-major [y][x]
+      std::vector<std::vector<Vector3f>> px((size_t)W, std::vector<Vector3f>((size_t)W));
+      Vector3f origin = fs.getCenter(); Vector2i size(W, W);
+      fs.updating_pixels(px, origin, size, 1, 0);
+      FILE* f = std::fopen("frame_square.bin", "wb");
+      for (int y = 0; y < W; ++y) for (int x = 0; x < W; ++x) std::fwrite(px[x][y].v, 4, 3, f);
+      std::fclose(f);
+      std::printf("frames %d\n", fs.framesRendered());
+    }
     // a frame that is not square (out of bounds in the reference), its viewport set like initialize does
     const int W2 = W + W / 2, H2 = W - W / 4;
     fs.getCamera()->setPerspectiveMatrix(60.0f, W2 / (float)H2, 0.1f, 100.0f);

@@ -90,6 +90,9 @@ def test_facade_matches_oracle(tmp_path, oa):
         l = next(it)
         assert l[0] == "rgb"
         assert np.allclose(f32(l[1:4]), rgb[i], rtol=1e-4, atol=1e-6)
+    # the batched overloads (one launch for all rays) gave the single-ray answers, element for element
+    l = next(it)
+    assert l == ["batched", str(n), "0"]
     # the leaf list as `boxes`, the primitive classes through their virtual intersects(Ray&), trace_global_illum
     l = next(it)
     assert l[0] == "boxes" and int(l[1]) == 4 and [int(x) for x in l[2:]] == [len(f) for _, _, f in o.leaves()]
@@ -141,6 +144,13 @@ def test_facade_matches_oracle(tmp_path, oa):
     w = np.array(want_txt[4:], np.int64)
     assert g.shape == w.shape and np.abs(g - w).max() <= 1      # 1e-4 relative on [0,1] floats can move a byte by one
     assert (g != w).mean() < 0.01
+    # result.ppm against the reference's OWN writer (Tucano::ImageImporter::writePPMImage compiled in place, oracle/_ref,
+    # shipped prebuilt) fed the float frame the facade rendered: the same file, byte for byte
+    frame = np.fromfile(tmp_path / "frame_square.bin", np.float32).reshape(W, W, 3)
+    if oa.ref() is not None and hasattr(oa.ref(), "ref_write_ppm"):
+        oa.ref_write_ppm(tmp_path / "ref_writer.ppm", frame)
+        assert open(tmp_path / "ref_writer.ppm", "rb").read() == open(tmp_path / "result_square.ppm", "rb").read()
+    assert ["frames", "1"] in lines          # the second updating_pixels call found the frame cached
     # a frame that is not square (the reference writes out of bounds there; the facade's [x][y] buffer has the
     # frame's own shape), rendered once by one scene handle and once as three parts of the tile grid on three handles
     # (rtx_render_multi through Flyscene::raytraceScene): the same file both times, equal to the oracle's frame
