@@ -338,8 +338,10 @@ int rtx_rgb_to_ppm8_dev(const float* rgb, uint64_t npixels, uint8_t* out, void* 
 
 /* Several GPUs in one process: Flyscene::raytraceScene's thread decomposition (src/flyscene.cpp:417-430,460:
  * 16 threads striding the rows of one frame) as nscenes parts of the tile grid, part i rendered by scenes[i]
- * on the device it was committed on -- all parts at once -- then copied to scenes[0]'s device (peer copies over
- * xGMI) and put back into row-major order there.  Every entry of `scenes` is a handle of its own holding the same
+ * on the device it was committed on -- all parts at once -- then moved to scenes[0]'s device over xGMI (grouped
+ * ncclSend / ncclRecv: RCCL is opened with dlopen the first time two handles of a call sit on different devices, so
+ * the library has no link-time dependency on it; hipMemcpyPeerAsync where RCCL cannot be had or with
+ * RTX_MULTI_GATHER=peer in the environment) and put back into row-major order there.  Every entry of `scenes` is a handle of its own holding the same
  * scene (rtx_scene_clone copies a scene's host description and its built BVH for the next device; two handles
  * may share a device).  Outputs as rtx_render: row-major [y - y0][x - x0], any may be NULL; host pointers for
  * rtx_render_multi, device pointers on scenes[0]'s device for rtx_render_multi_dev.  The frame is bit-identical

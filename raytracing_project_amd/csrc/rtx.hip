@@ -1725,6 +1725,77 @@ extern "C" int rtx_intersect_primitive(int device, int32_t kind, const float* pr
   return rc;
 }
 
+// ------------------------------------------------------------------ RCCL, loaded on demand
+// rtx_render_multi moves the tile parts of the other GPUs to the first scene's device with grouped ncclSend / ncclRecv
+// over xGMI (north star: "tiles gathered over xGMI with RCCL").  librccl is opened with dlopen the first time two
+// handles of one call sit on different devices -- not linked: a process that also holds PyTorch already has a copy of
+// the library loaded (torch ships its own), and the one dlopen finds by SONAME is that same copy, where a link-time
+// dependency would bring /opt/rocm's second one into the process.  Where the library or a communicator cannot be had
+// (or RTX_MULTI_GATHER=peer is set) the parts travel by hipMemcpyPeerAsync as before; results are identical.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <map>
+#include <mutex>
+namespace {
+struct Rccl {
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  bool ok = false;
+  std::string why;
+};
+std::mutex g_rccl_mu;
+Rccl* rccl_api() {                     // (callers hold g_rccl_mu)
+  static Rccl R;
+  static bool tried = false;
+  if (tried) return &R;
+  tried = true;
+  void* h = nullptr;
+  for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) { h = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+  if (!h) { R.why = std::string("dlopen(librccl): ") + (dlerror() ? dlerror() : "not found"); return &R; }
+  auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p && R.why.empty()) R.why = std::string("librccl lacks ") + n; return p; };
+  R.CommInitAll = (decltype(R.CommInitAll))sym("ncclCommInitAll");
+  R.CommDestroy = (decltype(R.CommDestroy))sym("ncclCommDestroy");
+  R.GroupStart = (decltype(R.GroupStart))sym("ncclGroupStart");
+  R.GroupEnd = (decltype(R.GroupEnd))sym("ncclGroupEnd");
+  R.Send = (decltype(R.Send))sym("ncclSend");
+  R.Recv = (decltype(R.Recv))sym("ncclRecv");
+  R.GetErrorString = (decltype(R.GetErrorString))sym("ncclGetErrorString");
+  R.ok = R.why.empty();
+  return &R;
+}
+// One communicator per set of devices (rank r of the set = its r-th device in ascending order), kept for the life of
+// the process: creating one costs hundreds of milliseconds.
+struct CommSet { std::vector<int> devs; std::vector<ncclComm_t> comms; };
+std::map<std::vector<int>, CommSet> g_comm_sets;
+CommSet* rccl_comms(const std::vector<int>& devs, std::string* why) {      // (callers hold g_rccl_mu)
+  Rccl* R = rccl_api();
+  if (!R->ok) { *why = R->why; return nullptr; }
+  auto it = g_comm_sets.find(devs);
+  if (it != g_comm_sets.end()) return it->second.comms.empty() ? nullptr : &it->second;
+  CommSet cs; cs.devs = devs; cs.comms.assign(devs.size(), nullptr);
+  const ncclResult_t rc = R->CommInitAll(cs.comms.data(), (int)devs.size(), devs.data());
+  if (rc != ncclSuccess) { *why = std::string("ncclCommInitAll: ") + R->GetErrorString(rc); cs.comms.clear(); }
+  CommSet* out = &(g_comm_sets[devs] = cs);
+  return out->comms.empty() ? nullptr : out;
+}
+bool multi_wants_rccl() {
+  static const bool peer = [] { const char* e = std::getenv("RTX_MULTI_GATHER"); return e && std::strcmp(e, "peer") == 0; }();
+  return !peer;
+}
+// (test hook) RTX_MULTI_GATHER=rccl-self: handles that share the first scene's device render into buffers of their own
+// and their parts go through a ncclSend / ncclRecv pair of that device's rank to itself -- the RCCL path (dlopen,
+// communicator, grouped calls, stream order) exercised on a box with one GPU.
+bool multi_self_test() {
+  static const bool self = [] { const char* e = std::getenv("RTX_MULTI_GATHER"); return e && std::strcmp(e, "rccl-self") == 0; }();
+  return self;
+}
+}  // namespace
+
 // ------------------------------------------------------------------ several GPUs, one process
 // A copy of a scene's host description and host-built acceleration data (no device state): what a caller commits
 // on another device without flattening the mesh and building the BVH again.
@@ -1744,8 +1815,9 @@ extern "C" int rtx_scene_clone(const rtx_scene* src, rtx_scene** out) {
 
 // Flyscene::raytraceScene's decomposition (src/flyscene.cpp:417-430,460: rows strided over 16 threads) over the
 // GPUs of one process: scene i renders part i of nscenes of the tile grid on its own device, all at once (each
-// scene has its own streams); the compact parts are copied to the first scene's device (peer copies over xGMI;
-// a plain device copy where two scenes share a device) and put back into row-major order there.
+// scene has its own streams); the compact parts of the other devices travel to the first scene's device over xGMI --
+// grouped ncclSend / ncclRecv (RCCL, above), peer copies where RCCL is not to be had; handles that share the first
+// scene's device render straight into the gather buffer -- and are put back into row-major order there.
 static int render_multi(rtx_scene* const* scenes, int32_t n, const rtx_camera* cam, const rtx_options* opt, rtx_rect rect,
                         int32_t tile_size, float* rgb, float* t, int32_t* face, bool host_out) {
   if (!scenes || n < 1) return fail(RTX_EINVAL, "need at least one scene");
@@ -1769,13 +1841,18 @@ static int render_multi(rtx_scene* const* scenes, int32_t n, const rtx_camera* c
     if (int rc = s0->m_gather[c].ensure((size_t)n * stride * words[c] * 4)) return rc;
     if (host_out) if (int rc = s0->w_io[c].ensure(npix * words[c] * 4)) return rc;
   }
+  // scene 0 (and any scene on its device) renders straight into its slot of the gather buffer; the others into a
+  // buffer on their own device, which is then moved
+  const bool self_test = multi_self_test();
+  auto moves = [&](int i) { return i > 0 && (scenes[i]->device != s0->device || self_test); };
   for (int i = 1; i < n; ++i) {
+    if (!moves(i)) continue;
     HIP_TRY(hipSetDevice(scenes[i]->device));
     for (int c = 0; c < 3; ++c) if (outs[c]) if (int rc = scenes[i]->m_part[c].ensure(stride * words[c] * 4)) return rc;
   }
-  auto part_ptr = [&](int i, int c) -> char* {      // scene 0 (and any scene on its device) renders straight into its slot of the gather buffer
+  auto part_ptr = [&](int i, int c) -> char* {
     if (!outs[c]) return nullptr;
-    if (scenes[i]->device == s0->device) return s0->m_gather[c].as<char>() + (size_t)i * stride * words[c] * 4;
+    if (!moves(i)) return s0->m_gather[c].as<char>() + (size_t)i * stride * words[c] * 4;
     return scenes[i]->m_part[c].as<char>();
   };
   // every part at once: the calls only queue work
@@ -1803,8 +1880,54 @@ static int render_multi(rtx_scene* const* scenes, int32_t n, const rtx_camera* c
   if (first_err) { g_err = err; return first_err; }
   HIP_TRY(hipSetDevice(s0->device));
   hipStream_t st = scenes[0]->slots[slot_of[0]].stream;
-  for (int i = 1; i < n; ++i) {
-    if (scenes[i]->device == s0->device) continue;
+  // ---- the parts of the other devices -> the first scene's device: RCCL send / recv pairs in one group (every part on
+  // its own link into device 0), else peer copies
+  bool any_move = false;
+  for (int i = 1; i < n; ++i) any_move = any_move || moves(i);
+  bool moved = false;
+  if (any_move && multi_wants_rccl()) {
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    std::vector<int> devs;
+    for (int i = 0; i < n; ++i) devs.push_back(scenes[i]->device);
+    std::sort(devs.begin(), devs.end());
+    devs.erase(std::unique(devs.begin(), devs.end()), devs.end());
+    std::string why;
+    CommSet* cs = rccl_comms(devs, &why);
+    if (cs) {
+      Rccl* R = rccl_api();
+      auto rank_of = [&](int dev) { return (int)(std::lower_bound(devs.begin(), devs.end(), dev) - devs.begin()); };
+      const int root = rank_of(s0->device);
+      // one stream per communicator: the root's is `st`; a sending device's is the stream of its first handle (the parts
+      // are finished -- the host has waited for them above -- so no stream has to wait for another, and the final
+      // synchronise of `st` below covers the senders: a part that has arrived has been read)
+      std::vector<hipStream_t> stream_of(devs.size(), nullptr);
+      stream_of[root] = st;
+      for (int i = 1; i < n; ++i) { const int r = rank_of(scenes[i]->device); if (!stream_of[r]) stream_of[r] = scenes[i]->slots[slot_of[i]].stream; }
+      ncclResult_t rc = R->GroupStart();
+      for (int i = 1; i < n && rc == ncclSuccess; ++i) {
+        if (!moves(i)) continue;
+        const int r = rank_of(scenes[i]->device);
+        for (int c = 0; c < 3 && rc == ncclSuccess; ++c) {
+          if (!outs[c]) continue;
+          const size_t bytes = (size_t)rtx_tiles_count(rect, tile_size, i, n) * tile_size * tile_size * words[c] * 4;
+          if (!bytes) continue;
+          rc = R->Send(scenes[i]->m_part[c].p, bytes, ncclChar, root, cs->comms[r], stream_of[r]);
+          if (rc == ncclSuccess)
+            rc = R->Recv(s0->m_gather[c].as<char>() + (size_t)i * stride * words[c] * 4, bytes, ncclChar, r, cs->comms[root], st);
+        }
+      }
+      const ncclResult_t rc_end = R->GroupEnd();
+      if (rc == ncclSuccess) rc = rc_end;
+      if (rc != ncclSuccess) return fail(RTX_EHIP, "RCCL gather of the tile parts: %s", R->GetErrorString(rc));
+      HIP_TRY(hipSetDevice(s0->device));
+      moved = true;
+    } else {
+      static bool told = false;
+      if (!told) { told = true; std::fprintf(stderr, "[rtx] rtx_render_multi: no RCCL (%s); the tile parts travel by peer copies\n", why.c_str()); }
+    }
+  }
+  for (int i = 1; i < n && !moved; ++i) {
+    if (!moves(i)) continue;
     for (int c = 0; c < 3; ++c) {
       if (!outs[c]) continue;
       const int nt = rtx_tiles_count(rect, tile_size, i, n);

@@ -108,3 +108,17 @@ def test_render_multi_full_size_soup(api):
     for c in clones:
         c.close()
     s.close()
+
+
+def test_render_multi_gathers_through_rccl(api):
+    """The RCCL gather of rtx_render_multi (grouped ncclSend / ncclRecv, librccl opened with dlopen) on the one-GPU box:
+    RTX_MULTI_GATHER=rccl-self routes the parts of the handles that share device 0 through send / recv pairs of rank 0 to
+    itself, so the library load, the communicator, the group and the stream order all run (scripts/multi_rccl_selftest.py,
+    a child process: the switch is read once per process).  Frames bit-equal to rtx_render's, two calls per part count."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "multi_rccl_selftest.py")], capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0 and "rccl-self ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "no RCCL" not in r.stderr, r.stderr[-1500:]          # the fallback to peer copies announces itself
