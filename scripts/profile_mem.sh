@@ -7,7 +7,7 @@ OUT=$ROOT/gpurun_out/mem_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $ROOT
-BENCH="python3 $ROOT/bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-roofline $*"
+BENCH="python3 $ROOT/bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-roofline --no-extras --repeats 1 $*"
 i=0
 for pass in "TA_TA_BUSY_sum TA_BUSY_avr TD_TD_BUSY_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE" \
             "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TD_TCP_STALL_CYCLES_sum TCP_TCP_LATENCY_sum GRBM_GUI_ACTIVE" \

@@ -13,6 +13,6 @@ OUT=gpurun_out/${TAG}_$WL.txt
 python3 scripts/prof_summary.py gpurun_out/prof_${TAG}_$WL > $OUT
 python3 scripts/prof_summary.py gpurun_out/mem_${TAG}_$WL >> $OUT
 python3 scripts/prof_derive.py $OUT >> $OUT.derived && cat $OUT.derived >> $OUT && rm $OUT.derived
-echo "command: python3 bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-roofline $ARGS" >> $OUT
+echo "command: python3 bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-roofline --no-extras --repeats 1 $ARGS" >> $OUT
 python3 scripts/prof_derive.py $OUT --pmc-json $WL > gpurun_out/${TAG}_${WL}_pmc.json
 tail -8 $OUT

@@ -7,7 +7,7 @@ OUT=$ROOT/gpurun_out/sq_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $ROOT
-BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline $*"
+BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extras --repeats 1 $*"
 i=0
 for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU" \
             "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INSTS_BRANCH" \
