@@ -13,5 +13,6 @@ timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WA
 timeout -s KILL 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $OUT/pmc_tcc -o pmc -- $BENCH > $OUT/pmc_tcc.log 2>&1 || { echo "pmc tcc failed"; tail -5 $OUT/pmc_tcc.log; exit 1; }
 python3 scripts/prof_summary.py $OUT > gpurun_out/pq_$TAG.txt
 python3 scripts/prof_derive.py gpurun_out/pq_$TAG.txt >> gpurun_out/pq_$TAG.txt
+rm -rf $OUT
 head -9 gpurun_out/pq_$TAG.txt | cut -c1-150
 grep -A12 "== derived" gpurun_out/pq_$TAG.txt | grep "k_trace\|k_shade\|k_resolve"
