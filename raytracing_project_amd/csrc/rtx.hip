@@ -610,6 +610,7 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   d.slights = s->d_slights.as<float4>(); d.leafboxes = s->d_leafboxes.as<float4>();
   d.leaf_faces = s->d_leaf_faces.as<int>(); d.face_pos = s->d_face_pos.as<int>();
   d.nsl = (uint32_t)(s->slights.size() / 4); d.nleafboxes = (uint32_t)nleaf;
+  d.sl_sin = sinf((float)(M_PI * 2 / 4)); d.sl_cos = cosf((float)(M_PI * 2 / 4));      // Shader::getNPointsOnCircle with n = 4
   d.flags = s->flags & RTX_FLAG_NO_ROOT_GATE; d.ntop = s->bvh.top_groups[kTopLevels];
   // Shader's shadowed branch (src/flyscene.cpp:731-743) colours a blocked light with the
   // *blocker's* Ka, Kd, Ks, Ns, d.  When every face and sphere has an in-range material and all
@@ -989,13 +990,13 @@ static int launch_trace_camera(rtx_scene* s, const DevCamera& C, uint32_t tiles,
   return RTX_OK;
 }
 static int launch_trace_queue(rtx_scene* s, const float4* rays, const uint32_t* count, uint32_t stride, uint64_t bound, uint2* hits,
-                              bool shadow = false, bool any_blocker = false, bool side = false) {
+                              bool shadow = false, bool any_blocker = false, bool side = false, bool compact = false) {
   hipStream_t on = side ? ws(s).stream2 : ws(s).stream;                        // side launches have their own overflow columns
   uint32_t* ovf = (side ? ws(s).w_stack_ovf2 : ws(s).w_stack_ovf).as<uint32_t>();
   const uint32_t grid = trace_blocks(s, ((bound + 63) / 64 * 64 * stride + kBlock - 1) / kBlock);
   const uint32_t grid_r = std::min<uint32_t>(grid, (uint32_t)s->ncu * RTX_BLOCKS_REFILL);
   const int mode = sched_pick(s, shadow ? KIND_SHADOW : KIND_BOUNCE, bound * stride);
-  const uint32_t bounded = shadow ? ((any_blocker ? 3u : 1u) | 4u) : 0u;      // 4: the queue is in shadow_index order
+  const uint32_t bounded = shadow ? ((any_blocker ? 3u : 1u) | 4u | (compact ? 8u : 0u)) : 0u;      // 4: the queue is in shadow_index order; 8: one hit point per parent
   const bool fast = (s->flags & RTX_FLAG_FAST_TRIANGLES) != 0;
   const uint32_t tri_min = mode == SCHED_REFILL_SPLIT ? kTriMinSplit : 1u;
   if (mode != SCHED_GROUPS) {
@@ -1342,7 +1343,7 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
     if (int rc = ws(s).w_parents.ensure((size_t)max_nodes * 4)) return rc;
     if (opt->shadows) {
       const size_t tiled = ((size_t)max_nodes + 63) / 64 * 64;          // shadow_index layout: whole groups of 64 parents
-      if (int rc = ws(s).w_shadow_rays.ensure(tiled * NLS * 32)) return rc;
+      if (int rc = ws(s).w_shadow_rays.ensure(tiled * 16)) return rc;                 // one hit point per parent (QueueSource forms the rays)
       if (int rc = ws(s).w_shadow_hits.ensure(tiled * NLS * 8)) return rc;
     }
     if (G) {
@@ -1425,7 +1426,7 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
     }
     if (opt->shadows && NLS) {
       span_begin(s, true);
-      if (int rc = launch_trace_queue(s, ws(s).w_shadow_rays.as<float4>(), cnt + 4 * g, NLS, bound, ws(s).w_shadow_hits.as<uint2>(), true, true)) return rc;
+      if (int rc = launch_trace_queue(s, ws(s).w_shadow_rays.as<float4>(), cnt + 4 * g, NLS, bound, ws(s).w_shadow_hits.as<uint2>(), true, true, false, true)) return rc;
       span_end(s, true);
     }
     if (G) {

@@ -91,6 +91,7 @@ struct DevScene {
   float root_lo[3], root_hi[3];   // Box(mesh) of the reference, used as its root gate
   uint32_t root_entry;            // traversal entry of the BVH root
   uint32_t nwild;                 // ill-conditioned triangles [ntris - nwild, ntris): tested by every ray
+  float sl_sin, sl_cos;           // sinf / cosf of (float)(2 pi / 4): the ring of Shader::getNPointsOnCircle (evaluated on the host, glibc)
 };
 
 struct DevCamera {
@@ -509,6 +510,37 @@ __device__ __forceinline__ bool node_step(const DevScene& S, const TopT& top, co
   return true;
 }
 
+// Eigen::AngleAxisf(theta, axis).toRotationMatrix() (Eigen/src/Geometry/AngleAxis.h:218-243), row-major
+__device__ __forceinline__ void angle_axis_matrix(float s, float c, V3 axis, float* m) {
+  const V3 sin_axis = s * axis;
+  const V3 cos1_axis = (1.0f - c) * axis;
+  float tmp;
+  tmp = cos1_axis.x * axis.y; m[1] = tmp - sin_axis.z; m[3] = tmp + sin_axis.z;
+  tmp = cos1_axis.x * axis.z; m[2] = tmp + sin_axis.y; m[6] = tmp - sin_axis.y;
+  tmp = cos1_axis.y * axis.z; m[5] = tmp - sin_axis.x; m[7] = tmp + sin_axis.x;
+  m[0] = cos1_axis.x * axis.x + c; m[4] = cos1_axis.y * axis.y + c; m[8] = cos1_axis.z * axis.z + c;
+}
+// Position of light sample ls seen from hit point P: the point lights, then per spherical
+// light the 4 ring points of Shader::getNPointsOnCircle + its centre (src/flyscene.cpp:616-626,
+// src/ShaderLib.h:11-31).  *fifth: the sample's colour is divided by 5 by the caller.
+__device__ __forceinline__ V3 light_sample_s(const DevScene& S, V3 P, uint32_t ls, bool* fifth) {
+  if (ls < S.nlights) { const float4 L = S.lights[ls]; *fifth = false; return v3(L.x, L.y, L.z); }
+  *fifth = true;
+  const uint32_t j = (ls - S.nlights) / 5u, k = (ls - S.nlights) % 5u;
+  const float4 sl = S.slights[j];
+  const V3 center = v3(sl.x, sl.y, sl.z);
+  if (k == 4u) return center;
+  const V3 normal = normalized(P - center);
+  V3 not_normal = v3(1.0f, 0.0f, 0.0f);
+  const bool eq = (normal.x == 1.0f && normal.y == 0.0f && normal.z == 0.0f) || (-normal.x == 1.0f && -normal.y == 0.0f && -normal.z == 0.0f);
+  if (eq) not_normal = normalized(v3(1.0f, 1.0f, 0.0f));
+  V3 rv = normalized(cross(normal, not_normal)) * sl.w;
+  float m[9];
+  angle_axis_matrix(S.sl_sin, S.sl_cos, normal, m);
+  for (uint32_t i = 0; i < k; ++i) rv = mat3_mul(m, rv);
+  return rv + center;
+}
+
 // Where a wave's rays come from.  get(j): ray j of the launch -> origin, Ray direction d1 and
 // the output slot of its hit record; false where index j holds no ray.
 // Traversal bound of a shadow ray: canSeeLight compares hit distances with |light - P|
@@ -545,10 +577,32 @@ struct QueueSource {
   uint32_t anyhit;     // shadow queue of a scene whose materials all shade a blocked light alike: any
                        // hit clearly before the light gives canSeeLight's answer *and* colour, so the
                        // ray stops there instead of looking for the closest one
+  // The pipeline's shadow queue (round 3): `rays` holds ONE 16-byte record per parent, its hit point; the ray of index j
+  // (shadow_index layout: 64 parents x one light sample per wave unit) is formed here from that point and light sample
+  // (j / 64) % tile_stride -- the expression k_shade used to evaluate and store as 64 bytes per ray.
+  const DevScene* scene = nullptr;      // != nullptr: compact records
   __device__ __forceinline__ bool first_hit_decides() const { return anyhit != 0; }
-  __device__ __forceinline__ float tmax_of(uint32_t slot) const { return rays[2 * (size_t)slot + 1].w; }
+  __device__ __forceinline__ uint32_t parent_of(uint32_t j) const { return (j / (64u * tile_stride)) * 64u + (j & 63u); }
+  __device__ __forceinline__ float tmax_of(uint32_t slot) const {
+    if (scene) {                          // (rare path: a shadow ray that holds a hit)
+      const float4 p = rays[parent_of(slot)];
+      const V3 P = v3(p.x, p.y, p.z);
+      bool fifth;
+      return shadow_tmax(light_sample_s(*scene, P, (slot >> 6) % tile_stride, &fifth), P);
+    }
+    return rays[2 * (size_t)slot + 1].w;
+  }
   __device__ __forceinline__ bool get(uint32_t j, V3* o, V3* d1, uint32_t* slot, float* tmax) const {
-    if (tile_stride != 0 && (j / (64u * tile_stride)) * 64u + (j & 63u) >= nparents) return false;
+    if (tile_stride != 0 && parent_of(j) >= nparents) return false;
+    if (scene) {
+      const float4 p = rays[parent_of(j)];
+      const V3 P = v3(p.x, p.y, p.z);
+      bool fifth;
+      const V3 L = light_sample_s(*scene, P, (j >> 6) % tile_stride, &fifth);       // (the light is the same for the 64 rays of a unit)
+      // canSeeLight: Ray(position, toLight.normalized()) normalises twice (src/flyscene.cpp:749-750)
+      *o = P; *d1 = normalized(normalized(L - P)); *slot = j; *tmax = shadow_tmax(L, P);
+      return true;
+    }
     const float4 ro = rays[2 * (size_t)j], rd = rays[2 * (size_t)j + 1];
     *o = v3(ro.x, ro.y, ro.z); *d1 = v3(rd.x, rd.y, rd.z); *slot = j;
     *tmax = bounded ? rd.w : INFINITY;
@@ -879,6 +933,7 @@ __global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_tra
   const uint32_t cnt = *count;
   uint32_t n = cnt * stride;
   if (bounded & 4u) { src.tile_stride = stride; src.nparents = cnt; n = ((cnt + 63u) & ~63u) * stride; }   // shadow_index layout
+  if (bounded & 8u) src.scene = &S;                                                                         // ... over one hit point per parent
   constexpr int kTop = kRefill ? kTopGroupsRefill : kTopGroups;
   __shared__ uint4 lds_top[kTop > 0 ? 4 * kTop : 1];
   const TopLevels<kTop> top = load_top_levels<kTop>(S, lds_top);
@@ -1165,37 +1220,7 @@ __device__ __forceinline__ DevMat material_of(const DevScene& S, int id) {
   return S.mats[id];
 }
 
-// Eigen::AngleAxisf(theta, axis).toRotationMatrix() (Eigen/src/Geometry/AngleAxis.h:218-243), row-major
-__device__ __forceinline__ void angle_axis_matrix(float s, float c, V3 axis, float* m) {
-  const V3 sin_axis = s * axis;
-  const V3 cos1_axis = (1.0f - c) * axis;
-  float tmp;
-  tmp = cos1_axis.x * axis.y; m[1] = tmp - sin_axis.z; m[3] = tmp + sin_axis.z;
-  tmp = cos1_axis.x * axis.z; m[2] = tmp + sin_axis.y; m[6] = tmp - sin_axis.y;
-  tmp = cos1_axis.y * axis.z; m[5] = tmp - sin_axis.x; m[7] = tmp + sin_axis.x;
-  m[0] = cos1_axis.x * axis.x + c; m[4] = cos1_axis.y * axis.y + c; m[8] = cos1_axis.z * axis.z + c;
-}
-// Position of light sample ls seen from hit point P: the point lights, then per spherical
-// light the 4 ring points of Shader::getNPointsOnCircle + its centre (src/flyscene.cpp:616-626,
-// src/ShaderLib.h:11-31).  *weight = 1 or 1/5 is applied by the caller as a division.
-__device__ __forceinline__ V3 light_sample(const PipeArgs& A, V3 P, uint32_t ls, bool* fifth) {
-  const DevScene& S = A.S;
-  if (ls < S.nlights) { const float4 L = S.lights[ls]; *fifth = false; return v3(L.x, L.y, L.z); }
-  *fifth = true;
-  const uint32_t j = (ls - S.nlights) / 5u, k = (ls - S.nlights) % 5u;
-  const float4 sl = S.slights[j];
-  const V3 center = v3(sl.x, sl.y, sl.z);
-  if (k == 4u) return center;
-  const V3 normal = normalized(P - center);
-  V3 not_normal = v3(1.0f, 0.0f, 0.0f);
-  const bool eq = (normal.x == 1.0f && normal.y == 0.0f && normal.z == 0.0f) || (-normal.x == 1.0f && -normal.y == 0.0f && -normal.z == 0.0f);
-  if (eq) not_normal = normalized(v3(1.0f, 1.0f, 0.0f));
-  V3 rv = normalized(cross(normal, not_normal)) * sl.w;
-  float m[9];
-  angle_axis_matrix(A.sl_sin, A.sl_cos, normal, m);
-  for (uint32_t i = 0; i < k; ++i) rv = mat3_mul(m, rv);
-  return rv + center;
-}
+__device__ __forceinline__ V3 light_sample(const PipeArgs& A, V3 P, uint32_t ls, bool* fifth) { return light_sample_s(A.S, P, ls, fifth); }
 __device__ __forceinline__ uint32_t light_samples(const DevScene& S) { return S.nlights + 5u * S.nsl; }
 
 // Ray::refractRay (src/Ray.h:36-42); pow(float,int) and sqrt run in double under libstdc++
@@ -1260,7 +1285,6 @@ __device__ __forceinline__ Spawn classify(const PipeArgs& A, uint32_t i) {
 __global__ __launch_bounds__(kBlock) void k_shade(PipeArgs A) {
   __shared__ uint32_t s_cnt[4], s_base[4], s_run[4];
   const uint32_t n = A.nrays ? *A.nrays : A.n0;
-  const uint32_t NLS = light_samples(A.S);
   const uint32_t per = (((n + gridDim.x - 1) / gridDim.x) + kBlock - 1) / kBlock * kBlock;
   const uint32_t beg = blockIdx.x * per < n ? blockIdx.x * per : n;
   const uint32_t end = beg + per < n ? beg + per : n;
@@ -1305,7 +1329,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(PipeArgs A) {
         long long* ax = A.acc + 3 * (size_t)r.pixel;
         ax[0] = acc_fixed(c0); ax[1] = acc_fixed(c1); ax[2] = acc_fixed(c1);
         A.acc_flag[r.pixel] = 0u;
-      } else {
+      } else if (!sp.hit) {               // (a hit pixel receives its first value from k_resolve: 0 + colour)
         float* px = A.rgb + 3 * (size_t)r.pixel;
         px[0] = c0; px[1] = c1; px[2] = c1;
       }
@@ -1317,17 +1341,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(PipeArgs A) {
     const uint32_t slot = s_base[0] + off_par;
     const Surface sf = surface_of(A.S, r.o, r.d1, sp.ht, sp.id);
     A.parents[slot] = i;
-    if (A.shadows) {
-      for (uint32_t ls = 0; ls < NLS; ++ls) {
-        bool fifth;
-        const V3 L = light_sample(A, sf.P, ls, &fifth);
-        // canSeeLight: Ray(position, toLight.normalized()) normalises twice (src/flyscene.cpp:749-750)
-        const V3 d1s = normalized(normalized(L - sf.P));
-        const size_t k = shadow_index(slot, ls, NLS);
-        A.shadow_rays[2 * k] = make_float4(sf.P.x, sf.P.y, sf.P.z, 0.0f);
-        A.shadow_rays[2 * k + 1] = make_float4(d1s.x, d1s.y, d1s.z, shadow_tmax(L, sf.P));
-      }
-    }
+    // the shadow rays of this parent: one record, its hit point (QueueSource forms the rays of every light sample from it)
+    if (A.shadows) A.shadow_rays[slot] = make_float4(sf.P.x, sf.P.y, sf.P.z, 0.0f);
     if (A.gi_rays > 0) {
       // Ray::resendRay (src/Ray.h:43-57): the reflected direction rotated about the normal
       float m[9];
@@ -1423,10 +1438,9 @@ __global__ __launch_bounds__(kBlock) void k_resolve(PipeArgs A) {
       const float dotted = dot(eye, normalized(reflectedLight));
       bool visible = true; int bmat = -1;
       if (A.shadows) {
-        const size_t k = shadow_index(h, ls, NLS);
-        const float4 sd = A.shadow_rays[2 * k + 1];
-        const uint2 sh = A.shadow_hits[k];
-        visible = can_see_light(A.S, light, sf.P, v3(sd.x, sd.y, sd.z), __uint_as_float(sh.x), (int)sh.y, &bmat);
+        // (the shadow ray's direction: the expression QueueSource formed it with, from the same light and point)
+        const uint2 sh = A.shadow_hits[shadow_index(h, ls, NLS)];
+        visible = can_see_light(A.S, light, sf.P, normalized(normalized(light - sf.P)), __uint_as_float(sh.x), (int)sh.y, &bmat);
       }
       const float ndl = dot(sf.N, lightDir);
       const float md = (ndl < 0.0f) ? 0.0f : ndl;          // std::max(a, b) = (a < b) ? b : a
@@ -1457,6 +1471,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(PipeArgs A) {
     float* px = A.rgb + 3 * (size_t)r.pixel;
     const V3 add = v3(r.thr * total.x, r.thr * total.y, r.thr * total.z);
     if (A.atomic_accum) { acc_add(A, r.pixel, 0, add.x); acc_add(A, r.pixel, 1, add.y); acc_add(A, r.pixel, 2, add.z); }
+    else if (A.first_gen) { px[0] = 0.0f + add.x; px[1] = 0.0f + add.y; px[2] = 0.0f + add.z; }      // the pixel's first node: traceRay's sum starts at zero
     else { px[0] += add.x; px[1] += add.y; px[2] += add.z; }
   }
 }

@@ -151,6 +151,9 @@ def main():
             sc.set_lights(lights, slights)
             if len(sph):
                 sc.set_spheres(sph, sph_mat)
+        if gi and len(T) > 6000:
+            gi = 0          # the reference's box split (host code, the reference's own cost) takes minutes from some 10 k faces
+                            # on: seed 3000137, 36 k faces, spent 4 silent minutes there and the run was taken for hung
         if gi:
             try:
                 nl = s.build_reference_leafboxes()
