@@ -560,7 +560,7 @@ struct CameraSource {
     return true;
   }
   __device__ __forceinline__ bool first_hit_decides() const { return false; }
-  __device__ __forceinline__ float tmax_of(uint32_t) const { return INFINITY; }
+  __device__ __forceinline__ float tmax_of(uint32_t, V3) const { return INFINITY; }
 };
 // Shadow rays of a node with several light samples: ray (parent p, sample ls) lives at shadow_index(p, ls, NLS) --
 // light-major within groups of 64 parents, so that the 64 rays of a wave unit go from 64 neighbouring hit points to
@@ -581,14 +581,23 @@ struct QueueSource {
   // (shadow_index layout: 64 parents x one light sample per wave unit) is formed here from that point and light sample
   // (j / 64) % tile_stride -- the expression k_shade used to evaluate and store as 64 bytes per ray.
   const DevScene* scene = nullptr;      // != nullptr: compact records
+  uint32_t magic = 0;                   // ceil(2^32 / tile_stride) where (j >> 6) / tile_stride == mulhi(j >> 6, magic); 0: divide
+  __device__ __forceinline__ void set_layout(uint32_t stride, uint32_t parents) {
+    tile_stride = stride; nparents = parents;
+    // exact while (j >> 6) * tile_stride < 2^32: queues are below 2^32 entries, so for up to 64 samples per parent
+    magic = (stride > 1u && stride <= 64u) ? 0xFFFFFFFFu / stride + 1u : 0u;
+  }
   __device__ __forceinline__ bool first_hit_decides() const { return anyhit != 0; }
-  __device__ __forceinline__ uint32_t parent_of(uint32_t j) const { return (j / (64u * tile_stride)) * 64u + (j & 63u); }
-  __device__ __forceinline__ float tmax_of(uint32_t slot) const {
-    if (scene) {                          // (rare path: a shadow ray that holds a hit)
-      const float4 p = rays[parent_of(slot)];
-      const V3 P = v3(p.x, p.y, p.z);
+  __device__ __forceinline__ uint32_t unit_parent(uint32_t unit) const {      // (unit = j >> 6) / tile_stride
+    return tile_stride == 1u ? unit : magic ? __umulhi(unit, magic) : unit / tile_stride;
+  }
+  __device__ __forceinline__ uint32_t parent_of(uint32_t j) const { return unit_parent(j >> 6) * 64u + (j & 63u); }
+  __device__ __forceinline__ uint32_t sample_of(uint32_t j) const { return tile_stride == 1u ? 0u : (j >> 6) - unit_parent(j >> 6) * tile_stride; }
+  // o: the ray's origin as get() returned it (compact records: the hit point, so |light - P| is formed from the same numbers again)
+  __device__ __forceinline__ float tmax_of(uint32_t slot, V3 o) const {
+    if (scene) {
       bool fifth;
-      return shadow_tmax(light_sample_s(*scene, P, (slot >> 6) % tile_stride, &fifth), P);
+      return shadow_tmax(light_sample_s(*scene, o, sample_of(slot), &fifth), o);
     }
     return rays[2 * (size_t)slot + 1].w;
   }
@@ -598,7 +607,7 @@ struct QueueSource {
       const float4 p = rays[parent_of(j)];
       const V3 P = v3(p.x, p.y, p.z);
       bool fifth;
-      const V3 L = light_sample_s(*scene, P, (j >> 6) % tile_stride, &fifth);       // (the light is the same for the 64 rays of a unit)
+      const V3 L = light_sample_s(*scene, P, sample_of(j), &fifth);       // (the light is the same for the 64 rays of a unit)
       // canSeeLight: Ray(position, toLight.normalized()) normalises twice (src/flyscene.cpp:749-750)
       *o = P; *d1 = normalized(normalized(L - P)); *slot = j; *tmax = shadow_tmax(L, P);
       return true;
@@ -666,6 +675,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& S, const TopLevels<kT
         Hit sb; sb.t = INFINITY; sb.id = -1;
         V3 sd = v3(0, 0, 0);
         if (j < chunk_end && src.get(j, &so, &sd1, &sslot, &sb.t)) {
+          const float tmax0 = sb.t;
           // spheres first, strict < (src/flyscene.cpp:523-532)
           for (uint32_t i = 0; i < S.nspheres; ++i) {
             const float t = ref_sphere_t(so, sd1, S.spheres[i]);
@@ -679,7 +689,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& S, const TopLevels<kT
               park = S.nwild != S.ntris && ray_is_finite(so, sd);
             }
           }
-          if (src.first_hit_decides() && sb.id != -1 && sb.t < 0.998f * src.tmax_of(sslot)) park = false;
+          if (src.first_hit_decides() && sb.id != -1 && sb.t < 0.998f * tmax0) park = false;
           if (!park) hits[sslot] = make_uint2(__float_as_uint(sb.id == -1 ? INFINITY : sb.t), (uint32_t)sb.id);
         }
         const uint64_t pm = __ballot(park);
@@ -756,7 +766,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& S, const TopLevels<kT
         const uint32_t rest = cnt != 0 ? (0x80000000u | (cnt << 28) | first) : kDone;
         if (has_pend) pend = rest; else if (cnt != 0) cur = rest; else pop = true;
         // tmax = 1.001 |light - P|: a hit below 0.998 tmax is before the light whatever the rounding
-        if (src.first_hit_decides() && best.id != -1 && best.t < 0.998f * src.tmax_of(slot)) { sp = 0; cur = kDone; pend = kDone; pop = false; }
+        if (src.first_hit_decides() && best.id != -1 && best.t < 0.998f * src.tmax_of(slot, o)) { sp = 0; cur = kDone; pend = kDone; pop = false; }
       }
     }
     if (RTX_SPEC != 0 && (RTX_SPEC == 1 || !src.first_hit_decides()) && (int)cur < 0 && pend == kDone) { pend = cur; pop = true; }
@@ -783,6 +793,7 @@ __device__ __forceinline__ void trace_wave_groups(const DevScene& S, const TopLe
       V3 o, d1; uint32_t slot;
       Hit best; best.id = -1;
       if (!src.get(j, &o, &d1, &slot, &best.t)) continue;
+      const float tmax0 = best.t;
       for (uint32_t i = 0; i < S.nspheres; ++i) {
         const float t = ref_sphere_t(o, d1, S.spheres[i]);
         if (t != INFINITY && t < best.t) { best.t = t; best.id = -2 - (int)i; }
@@ -796,7 +807,7 @@ __device__ __forceinline__ void trace_wave_groups(const DevScene& S, const TopLe
           walk = S.nwild != S.ntris && ray_is_finite(o, d);
         }
       }
-      if (src.first_hit_decides() && best.id != -1 && best.t < 0.998f * src.tmax_of(slot)) walk = false;
+      if (src.first_hit_decides() && best.id != -1 && best.t < 0.998f * tmax0) walk = false;
       if (walk) {
         const float ivx = cull_inv(d.x), ivy = cull_inv(d.y), ivz = cull_inv(d.z);
         const float oix = o.x * ivx, oiy = o.y * ivy, oiz = o.z * ivz;
@@ -808,7 +819,7 @@ __device__ __forceinline__ void trace_wave_groups(const DevScene& S, const TopLe
           } else {
             const uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
             for (uint32_t k = first; k < first + cnt; ++k) Tri::test(S, k, o, d, &best);
-            if (src.first_hit_decides() && best.id != -1 && best.t < 0.998f * src.tmax_of(slot)) break;
+            if (src.first_hit_decides() && best.id != -1 && best.t < 0.998f * tmax0) break;
           }
           if (sp == 0) break;
           --sp;
@@ -932,7 +943,7 @@ __global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_tra
   QueueSource src; src.rays = rays; src.bounded = bounded; src.anyhit = ((bounded & 2u) && (S.flags & 2u)) ? 1u : 0u;
   const uint32_t cnt = *count;
   uint32_t n = cnt * stride;
-  if (bounded & 4u) { src.tile_stride = stride; src.nparents = cnt; n = ((cnt + 63u) & ~63u) * stride; }   // shadow_index layout
+  if (bounded & 4u) { src.set_layout(stride, cnt); n = ((cnt + 63u) & ~63u) * stride; }   // shadow_index layout
   if (bounded & 8u) src.scene = &S;                                                                         // ... over one hit point per parent
   constexpr int kTop = kRefill ? kTopGroupsRefill : kTopGroups;
   __shared__ uint4 lds_top[kTop > 0 ? 4 * kTop : 1];
