@@ -560,7 +560,7 @@ struct CameraSource {
     return true;
   }
   __device__ __forceinline__ bool first_hit_decides() const { return false; }
-  __device__ __forceinline__ float tmax_of(uint32_t, V3) const { return INFINITY; }
+  __device__ __forceinline__ bool decides(uint32_t, V3, float) const { return false; }
 };
 // Shadow rays of a node with several light samples: ray (parent p, sample ls) lives at shadow_index(p, ls, NLS) --
 // light-major within groups of 64 parents, so that the 64 rays of a wave unit go from 64 neighbouring hit points to
@@ -593,13 +593,22 @@ struct QueueSource {
   }
   __device__ __forceinline__ uint32_t parent_of(uint32_t j) const { return unit_parent(j >> 6) * 64u + (j & 63u); }
   __device__ __forceinline__ uint32_t sample_of(uint32_t j) const { return tile_stride == 1u ? 0u : (j >> 6) - unit_parent(j >> 6) * tile_stride; }
-  // o: the ray's origin as get() returned it (compact records: the hit point, so |light - P| is formed from the same numbers again)
-  __device__ __forceinline__ float tmax_of(uint32_t slot, V3 o) const {
+  // Does a hit at distance t end the search of a ray whose first hit decides (t clearly before the light: tmax = 1.001 |light - P|,
+  // and a hit below 0.998 tmax is before the light whatever the rounding)?  o: the ray's origin as get() returned it.  Compact
+  // records hold no tmax: for a point light the test is made on squares, t^2 < 0.995 |light - o|^2, i.e. t < 0.9975 |light - o| --
+  // a little stricter, no square root; which hits end a search early does not show in the result (any blocker shades alike).
+  __device__ __forceinline__ bool decides(uint32_t slot, V3 o, float t) const {
     if (scene) {
+      const uint32_t ls = sample_of(slot);
+      if (ls < scene->nlights) {
+        const float4 L = scene->lights[ls];
+        const V3 v = v3(L.x, L.y, L.z) - o;
+        return t * t < 0.995f * dot(v, v);
+      }
       bool fifth;
-      return shadow_tmax(light_sample_s(*scene, o, sample_of(slot), &fifth), o);
+      return t < 0.998f * shadow_tmax(light_sample_s(*scene, o, ls, &fifth), o);
     }
-    return rays[2 * (size_t)slot + 1].w;
+    return t < 0.998f * rays[2 * (size_t)slot + 1].w;
   }
   __device__ __forceinline__ bool get(uint32_t j, V3* o, V3* d1, uint32_t* slot, float* tmax) const {
     if (tile_stride != 0 && parent_of(j) >= nparents) return false;
@@ -766,7 +775,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& S, const TopLevels<kT
         const uint32_t rest = cnt != 0 ? (0x80000000u | (cnt << 28) | first) : kDone;
         if (has_pend) pend = rest; else if (cnt != 0) cur = rest; else pop = true;
         // tmax = 1.001 |light - P|: a hit below 0.998 tmax is before the light whatever the rounding
-        if (src.first_hit_decides() && best.id != -1 && best.t < 0.998f * src.tmax_of(slot, o)) { sp = 0; cur = kDone; pend = kDone; pop = false; }
+        if (src.first_hit_decides() && best.id != -1 && src.decides(slot, o, best.t)) { sp = 0; cur = kDone; pend = kDone; pop = false; }
       }
     }
     if (RTX_SPEC != 0 && (RTX_SPEC == 1 || !src.first_hit_decides()) && (int)cur < 0 && pend == kDone) { pend = cur; pop = true; }
