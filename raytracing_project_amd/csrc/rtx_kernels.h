@@ -1359,7 +1359,11 @@ __global__ __launch_bounds__(kBlock) void k_shade(PipeArgs A) {
     const uint32_t off_t = wave_alloc_lds(sp.refr, &s_run[1]);
     if (!sp.hit) continue;
     const uint32_t slot = s_base[0] + off_par;
-    const Surface sf = surface_of(A.S, r.o, r.d1, sp.ht, sp.id);
+    // the hit point alone where that is all a parent needs (its shadow record): the normal and the material are a gather from the
+    // per-face table, wanted by GI probes and child rays only
+    Surface sf;
+    if (A.gi_rays > 0 || sp.refl || sp.refr) sf = surface_of(A.S, r.o, r.d1, sp.ht, sp.id);
+    else { sf.P = point_on_ray(r.o, sp.id >= 0 ? normalized(r.d1) : r.d1, sp.ht); sf.N = v3(0, 0, 0); sf.mat = -1; }
     A.parents[slot] = i;
     // the shadow rays of this parent: one record, its hit point (QueueSource forms the rays of every light sample from it)
     if (A.shadows) A.shadow_rays[slot] = make_float4(sf.P.x, sf.P.y, sf.P.z, 0.0f);
