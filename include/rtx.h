@@ -140,6 +140,11 @@ int rtx_scene_set_lights(rtx_scene*, const float* xyz, uint32_t n, const float* 
  * Off by default: the default path is the reference's arithmetic.  With RTX_FLAG_VERIFY the sampled re-check (always
  * in the reference's arithmetic) counts those differences in rtx_stats.verify_mismatches. */
 #define RTX_FLAG_FAST_TRIANGLES 32u
+/* RTX_FLAG_PARENT_LIST: a diagnostic switch without effect on results.  A camera frame whose nodes spawn nothing but shadow
+ * rays (no reflection / refraction generations, no GI probes) is shaded straight from its hit records: the shadow launch walks
+ * the output slots, no compacted parent list is made.  With this flag such frames take the general path (parent list, one
+ * hit-point record per parent), as frames with child rays always do; the two give the same pixels bit for bit (tested). */
+#define RTX_FLAG_PARENT_LIST 64u
 int rtx_scene_set_flags(rtx_scene*, uint32_t flags);
 
 /* Flyscene::divideBox_KD + averagePoint / axisToDivide / isInBox and Box(mesh)

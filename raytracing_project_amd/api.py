@@ -58,7 +58,7 @@ SYMBOLS = ["rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_
 
 MAX_BATCH = 64
 NOALLOC_MAX_RAYS = 65536
-FLAG_NO_ROOT_GATE, FLAG_SCHED_REFILL, FLAG_SCHED_GROUPS, FLAG_SCHED_SPLIT, FLAG_VERIFY, FLAG_FAST_TRIANGLES = 1, 2, 4, 8, 16, 32
+FLAG_NO_ROOT_GATE, FLAG_SCHED_REFILL, FLAG_SCHED_GROUPS, FLAG_SCHED_SPLIT, FLAG_VERIFY, FLAG_FAST_TRIANGLES, FLAG_PARENT_LIST = 1, 2, 4, 8, 16, 32, 64
 
 _lib = None
 

@@ -111,11 +111,12 @@ struct rtx_scene {
     DevBuf w_stack_ovf;                // global overflow columns of the per-lane traversal stacks
     DevBuf w_stack_ovf2;               // ... of the launches on stream2 (they run beside launches on `stream`)
     DevBuf w_rays[2], w_hits[3], w_parents, w_shadow_rays, w_shadow_hits, w_gi_rays, w_gi_hits, w_counters;
+    DevBuf w_camera;                   // device copy of a call's DevCamera (run_pipeline's direct mode: k_trace_shadow_direct reads it)
     DevBuf w_guard;                    // counters of the domain guard / verification kernels
     DevBuf w_acc, w_acc_flag;          // fixed-point pixel sums of ray-tree calls (reflection + refraction)
     template <class F> void for_each_buf(F f) {
       f(w_cam_tab); f(w_frames); f(w_stack_ovf); f(w_stack_ovf2); f(w_rays[0]); f(w_rays[1]); f(w_hits[0]); f(w_hits[1]); f(w_hits[2]);
-      f(w_parents); f(w_shadow_rays); f(w_shadow_hits); f(w_gi_rays); f(w_gi_hits); f(w_counters); f(w_acc); f(w_acc_flag); f(w_guard);
+      f(w_camera); f(w_parents); f(w_shadow_rays); f(w_shadow_hits); f(w_gi_rays); f(w_gi_hits); f(w_counters); f(w_acc); f(w_acc_flag); f(w_guard);
     }
   };
   Slot slots[kSlots];
@@ -249,7 +250,7 @@ extern "C" int rtx_scene_set_spheres(rtx_scene* s, const float* cr4, const int32
 
 extern "C" int rtx_scene_set_flags(rtx_scene* s, uint32_t flags) {
   if (!s) return fail(RTX_EINVAL, "null scene");
-  if (flags & ~(uint32_t)(RTX_FLAG_NO_ROOT_GATE | RTX_FLAG_SCHED_REFILL | RTX_FLAG_SCHED_GROUPS | RTX_FLAG_SCHED_SPLIT | RTX_FLAG_VERIFY | RTX_FLAG_FAST_TRIANGLES))
+  if (flags & ~(uint32_t)(RTX_FLAG_NO_ROOT_GATE | RTX_FLAG_SCHED_REFILL | RTX_FLAG_SCHED_GROUPS | RTX_FLAG_SCHED_SPLIT | RTX_FLAG_VERIFY | RTX_FLAG_FAST_TRIANGLES | RTX_FLAG_PARENT_LIST))
     return fail(RTX_EINVAL, "unknown flag bits 0x%x", flags);
   if ((flags & RTX_FLAG_SCHED_REFILL) && (flags & RTX_FLAG_SCHED_GROUPS)) return fail(RTX_EINVAL, "pick one scheduler");
   if ((flags & RTX_FLAG_SCHED_SPLIT) && !(flags & RTX_FLAG_SCHED_REFILL)) return fail(RTX_EINVAL, "RTX_FLAG_SCHED_SPLIT modifies RTX_FLAG_SCHED_REFILL");
@@ -1009,6 +1010,26 @@ static int launch_trace_queue(rtx_scene* s, const float4* rays, const uint32_t* 
   return RTX_OK;
 }
 
+// The shadow launch of a camera frame without a parent list (run_pipeline's direct mode): every output slot x light sample.
+static int launch_trace_shadow_direct(rtx_scene* s, const DevCamera* cam_dev, const uint2* hits0, uint32_t nslots, uint32_t nls, uint2* hits) {
+  const uint64_t bound = (uint64_t)nslots;
+  const uint32_t grid = trace_blocks(s, ((bound + 63) / 64 * 64 * nls + kBlock - 1) / kBlock);
+  const uint32_t grid_r = std::min<uint32_t>(grid, (uint32_t)s->ncu * RTX_BLOCKS_REFILL);
+  const int mode = sched_pick(s, KIND_SHADOW, bound * nls);
+  const bool fast = (s->flags & RTX_FLAG_FAST_TRIANGLES) != 0;
+  const uint32_t tri_min = mode == SCHED_REFILL_SPLIT ? kTriMinSplit : 1u;
+  uint32_t* ovf = ws(s).w_stack_ovf.as<uint32_t>();
+  hipStream_t on = ws(s).stream;
+  if (mode != SCHED_GROUPS) {
+    if (fast) hipLaunchKernelGGL((k_trace_shadow_direct<true, FastTri>), dim3(grid_r), dim3(kBlock), 0, on, s->dev, cam_dev, hits0, nslots, nls, 1u, grab_size(), tri_min, ovf, hits);
+    else hipLaunchKernelGGL((k_trace_shadow_direct<true, RefTri>), dim3(grid_r), dim3(kBlock), 0, on, s->dev, cam_dev, hits0, nslots, nls, 1u, grab_size(), tri_min, ovf, hits);
+  } else {
+    if (fast) hipLaunchKernelGGL((k_trace_shadow_direct<false, FastTri>), dim3(grid), dim3(kBlock), 0, on, s->dev, cam_dev, hits0, nslots, nls, 1u, grab_size(), 1u, ovf, hits);
+    else hipLaunchKernelGGL((k_trace_shadow_direct<false, RefTri>), dim3(grid), dim3(kBlock), 0, on, s->dev, cam_dev, hits0, nslots, nls, 1u, grab_size(), 1u, ovf, hits);
+  }
+  return RTX_OK;
+}
+
 // Traces `n` caller rays held on the device (xyz arrays) into w_hits[0]; w_rays[0] keeps the records.
 static int trace_rays_dev(rtx_scene* s, const float* d_o, const float* d_d, uint32_t n) {
   if (int rc = ws(s).w_rays[0].ensure((size_t)n * 32)) return rc;
@@ -1339,12 +1360,19 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
   // ray indices are 32-bit in the kernels and a wave's next unit may lie up to one grid of units past the end
   if ((max_nodes + 64) * std::max<uint64_t>(std::max(NLS, G), 1) >= (1ull << 31)) return fail(RTX_ELIMIT, "ray queue would exceed 2^31 entries");
   if (int rc = ws(s).w_hits[0].ensure((size_t)pr.n0 * 8)) return rc;
+  // Direct mode: a camera frame whose nodes spawn nothing but shadow rays (no reflection / refraction generations, no GI probes)
+  // needs no parent list -- the shadow launch walks the output slots and takes the hit ones (DirectSource), k_resolve_direct shades
+  // every slot; k_shade's two passes over all slots, the parent list and the hit-point records are not made at all.  Same pixels,
+  // bit for bit (RTX_FLAG_PARENT_LIST or RTX_DIRECT=0 keep the list; tests/test_gpu_direct.py renders both ways).
+  static const bool direct_ok = [] { const char* e = std::getenv("RTX_DIRECT"); return !(e && std::atoi(e) == 0); }();
+  const bool direct = direct_ok && !(s->flags & RTX_FLAG_PARENT_LIST) && pr.camera && shade && max_gen == 0 && G == 0 && !tree;
   if (shade) {
-    if (int rc = ws(s).w_parents.ensure((size_t)max_nodes * 4)) return rc;
+    if (!direct) { if (int rc = ws(s).w_parents.ensure((size_t)max_nodes * 4)) return rc; }
     if (opt->shadows) {
       const size_t tiled = ((size_t)max_nodes + 63) / 64 * 64;          // shadow_index layout: whole groups of 64 parents
-      if (int rc = ws(s).w_shadow_rays.ensure(tiled * 16)) return rc;                 // one hit point per parent (QueueSource forms the rays)
+      if (!direct) { if (int rc = ws(s).w_shadow_rays.ensure(tiled * 16)) return rc; }                // one hit point per parent (QueueSource forms the rays)
       if (int rc = ws(s).w_shadow_hits.ensure(tiled * NLS * 8)) return rc;
+      if (direct) { if (int rc = ws(s).w_camera.ensure(sizeof(DevCamera))) return rc; }
     }
     if (G) {
       if (int rc = ws(s).w_gi_rays.ensure((size_t)max_nodes * G * 32)) return rc;
@@ -1405,6 +1433,16 @@ static int run_pipeline(rtx_scene* s, const Primary& pr, const rtx_options* opt,
     A.counters = cnt + 4 * g;
     A.acc = ws(s).w_acc.as<long long>(); A.acc_flag = ws(s).w_acc_flag.as<uint32_t>();
     A.gi_sin = sinf(th_gi); A.gi_cos = cosf(th_gi); A.sl_sin = sinf(th_sl); A.sl_cos = cosf(th_sl);
+    if (direct) {
+      if (opt->shadows && NLS) {
+        hipLaunchKernelGGL(k_store_camera, dim3(1), dim3(64), 0, ws(s).stream, pr.C, ws(s).w_camera.as<DevCamera>());
+        span_begin(s, true);
+        if (int rc = launch_trace_shadow_direct(s, ws(s).w_camera.as<DevCamera>(), A.hits, pr.n0, NLS, ws(s).w_shadow_hits.as<uint2>())) return rc;
+        span_end(s, true);
+      }
+      hipLaunchKernelGGL(k_resolve_direct, dim3(grid_for(s, pr.n0)), dim3(kBlock), 0, ws(s).stream, A);
+      break;
+    }
     hipLaunchKernelGGL(k_shade, dim3(grid_for(s, bound)), dim3(kBlock), 0, ws(s).stream, A);
     if (!shade) break;
     // The bounce rays of generation g+1 and the shadow rays of g both come out of k_shade and do not depend on

@@ -569,10 +569,44 @@ struct CameraSource {
 __device__ __forceinline__ size_t shadow_index(uint32_t parent, uint32_t ls, uint32_t nls) {
   return (size_t)(parent >> 6) * 64u * nls + (size_t)ls * 64u + (parent & 63u);
 }
-struct QueueSource {
-  const float4* rays;
+// Index arithmetic of a queue in shadow_index order: (parent, light sample) of entry j.
+struct ShadowLayout {
   uint32_t tile_stride = 0;   // != 0: shadow_index layout with this many samples per parent, nparents parents
   uint32_t nparents = 0;
+  uint32_t magic = 0;         // ceil(2^32 / tile_stride) where (j >> 6) / tile_stride == mulhi(j >> 6, magic); 0: divide
+  __device__ __forceinline__ void set_layout(uint32_t stride, uint32_t parents) {
+    tile_stride = stride; nparents = parents;
+    // exact while (j >> 6) * tile_stride < 2^32: queues are below 2^32 entries, so for up to 64 samples per parent
+    magic = (stride > 1u && stride <= 64u) ? 0xFFFFFFFFu / stride + 1u : 0u;
+  }
+  __device__ __forceinline__ uint32_t unit_parent(uint32_t unit) const {      // (unit = j >> 6) / tile_stride
+    return tile_stride == 1u ? unit : magic ? __umulhi(unit, magic) : unit / tile_stride;
+  }
+  __device__ __forceinline__ uint32_t parent_of(uint32_t j) const { return unit_parent(j >> 6) * 64u + (j & 63u); }
+  __device__ __forceinline__ uint32_t sample_of(uint32_t j) const { return tile_stride == 1u ? 0u : (j >> 6) - unit_parent(j >> 6) * tile_stride; }
+};
+// Does a hit at distance t end the search of a shadow ray whose first hit decides (t clearly before the light: tmax = 1.001 |light - P|,
+// and a hit below 0.998 tmax is before the light whatever the rounding)?  o: the ray's origin, which IS the hit point P the ray was
+// formed from.  For a point light the test is made on squares, t^2 < 0.995 |light - o|^2, i.e. t < 0.9975 |light - o| -- a little
+// stricter, no square root; which hits end a search early does not show in the result (any blocker shades alike).
+__device__ __forceinline__ bool shadow_hit_decides(const DevScene& S, uint32_t ls, V3 o, float t) {
+  if (ls < S.nlights) {
+    const float4 L = S.lights[ls];
+    const V3 v = v3(L.x, L.y, L.z) - o;
+    return t * t < 0.995f * dot(v, v);
+  }
+  bool fifth;
+  return t < 0.998f * shadow_tmax(light_sample_s(S, o, ls, &fifth), o);
+}
+// The shadow ray from hit point P towards light sample ls, as canSeeLight forms it: Ray(position, toLight.normalized()) normalises
+// twice (src/flyscene.cpp:749-750).
+__device__ __forceinline__ void shadow_ray_of(const DevScene& S, V3 P, uint32_t ls, V3* o, V3* d1, float* tmax) {
+  bool fifth;
+  const V3 L = light_sample_s(S, P, ls, &fifth);
+  *o = P; *d1 = normalized(normalized(L - P)); *tmax = shadow_tmax(L, P);
+}
+struct QueueSource : ShadowLayout {
+  const float4* rays;
   uint32_t bounded;    // rd.w of the records is tmax (shadow queue) rather than a throughput
   uint32_t anyhit;     // shadow queue of a scene whose materials all shade a blocked light alike: any
                        // hit clearly before the light gives canSeeLight's answer *and* colour, so the
@@ -581,49 +615,49 @@ struct QueueSource {
   // (shadow_index layout: 64 parents x one light sample per wave unit) is formed here from that point and light sample
   // (j / 64) % tile_stride -- the expression k_shade used to evaluate and store as 64 bytes per ray.
   const DevScene* scene = nullptr;      // != nullptr: compact records
-  uint32_t magic = 0;                   // ceil(2^32 / tile_stride) where (j >> 6) / tile_stride == mulhi(j >> 6, magic); 0: divide
-  __device__ __forceinline__ void set_layout(uint32_t stride, uint32_t parents) {
-    tile_stride = stride; nparents = parents;
-    // exact while (j >> 6) * tile_stride < 2^32: queues are below 2^32 entries, so for up to 64 samples per parent
-    magic = (stride > 1u && stride <= 64u) ? 0xFFFFFFFFu / stride + 1u : 0u;
-  }
   __device__ __forceinline__ bool first_hit_decides() const { return anyhit != 0; }
-  __device__ __forceinline__ uint32_t unit_parent(uint32_t unit) const {      // (unit = j >> 6) / tile_stride
-    return tile_stride == 1u ? unit : magic ? __umulhi(unit, magic) : unit / tile_stride;
-  }
-  __device__ __forceinline__ uint32_t parent_of(uint32_t j) const { return unit_parent(j >> 6) * 64u + (j & 63u); }
-  __device__ __forceinline__ uint32_t sample_of(uint32_t j) const { return tile_stride == 1u ? 0u : (j >> 6) - unit_parent(j >> 6) * tile_stride; }
-  // Does a hit at distance t end the search of a ray whose first hit decides (t clearly before the light: tmax = 1.001 |light - P|,
-  // and a hit below 0.998 tmax is before the light whatever the rounding)?  o: the ray's origin as get() returned it.  Compact
-  // records hold no tmax: for a point light the test is made on squares, t^2 < 0.995 |light - o|^2, i.e. t < 0.9975 |light - o| --
-  // a little stricter, no square root; which hits end a search early does not show in the result (any blocker shades alike).
   __device__ __forceinline__ bool decides(uint32_t slot, V3 o, float t) const {
-    if (scene) {
-      const uint32_t ls = sample_of(slot);
-      if (ls < scene->nlights) {
-        const float4 L = scene->lights[ls];
-        const V3 v = v3(L.x, L.y, L.z) - o;
-        return t * t < 0.995f * dot(v, v);
-      }
-      bool fifth;
-      return t < 0.998f * shadow_tmax(light_sample_s(*scene, o, ls, &fifth), o);
-    }
+    if (scene) return shadow_hit_decides(*scene, sample_of(slot), o, t);     // (compact records hold no tmax)
     return t < 0.998f * rays[2 * (size_t)slot + 1].w;
   }
   __device__ __forceinline__ bool get(uint32_t j, V3* o, V3* d1, uint32_t* slot, float* tmax) const {
     if (tile_stride != 0 && parent_of(j) >= nparents) return false;
     if (scene) {
       const float4 p = rays[parent_of(j)];
-      const V3 P = v3(p.x, p.y, p.z);
-      bool fifth;
-      const V3 L = light_sample_s(*scene, P, sample_of(j), &fifth);       // (the light is the same for the 64 rays of a unit)
-      // canSeeLight: Ray(position, toLight.normalized()) normalises twice (src/flyscene.cpp:749-750)
-      *o = P; *d1 = normalized(normalized(L - P)); *slot = j; *tmax = shadow_tmax(L, P);
+      shadow_ray_of(*scene, v3(p.x, p.y, p.z), sample_of(j), o, d1, tmax);       // (the light is the same for the 64 rays of a unit)
+      *slot = j;
       return true;
     }
     const float4 ro = rays[2 * (size_t)j], rd = rays[2 * (size_t)j + 1];
     *o = v3(ro.x, ro.y, ro.z); *d1 = v3(rd.x, rd.y, rd.z); *slot = j;
     *tmax = bounded ? rd.w : INFINITY;
+    return true;
+  }
+};
+
+// The shadow rays of a camera frame WITHOUT a parent list (frames whose nodes spawn no children: no reflection / refraction / GI):
+// queue index j is (output slot p, light sample ls) in shadow_index order over ALL slots of the call; a slot whose camera ray hit
+// something gives a ray -- its hit point is formed again from the camera ray and the hit distance, the expressions of surface_of --
+// and the others give none.  The refilling scheduler's parked-ray buffer does the compaction k_shade's two passes did.
+struct DirectSource : ShadowLayout {
+  const DevCamera* C;       // device copy: read in the set-up of a chunk only
+  const uint2* hits0;       // closest hits of the camera rays, per slot (dead slots of the tiled layout hold anything)
+  const DevScene* scene;
+  uint32_t anyhit;
+  __device__ __forceinline__ bool first_hit_decides() const { return anyhit != 0; }
+  __device__ __forceinline__ bool decides(uint32_t slot, V3 o, float t) const { return shadow_hit_decides(*scene, sample_of(slot), o, t); }
+  __device__ __forceinline__ bool get(uint32_t j, V3* o, V3* d1, uint32_t* slot, float* tmax) const {
+    const uint32_t p = parent_of(j);
+    if (p >= nparents) return false;
+    const uint2 h = hits0[p];
+    const int id = (int)h.y;
+    uint32_t f; int x, y;
+    if (!slot_pixel(*C, p, &f, &x, &y) || id == -1) return false;
+    V3 co, cd1;
+    camera_ray(*C, f, x, y, &co, &cd1);
+    const V3 P = point_on_ray(co, id >= 0 ? normalized(cd1) : cd1, __uint_as_float(h.x));      // surface_of's hit point
+    shadow_ray_of(*scene, P, sample_of(j), o, d1, tmax);
+    *slot = j;
     return true;
   }
 };
@@ -965,6 +999,30 @@ __global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_tra
   } else {
     trace_wave_groups<Tri>(S, top, src, work, make_stack<kLdsStackGroups>(lds_stack, ovf), hits);
   }
+}
+
+// Shadow rays of a camera frame straight from its hit records (DirectSource): nslots output slots x nls light samples.
+template <bool kRefill, class Tri = RefTri>
+__global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_trace_shadow_direct(DevScene S, const DevCamera* C, const uint2* hits0, uint32_t nslots,
+                                                         uint32_t nls, uint32_t any_blocker, uint32_t grab, uint32_t tri_min, uint32_t* ovf, uint2* hits) {
+  __shared__ uint32_t lds_stack[(kRefill ? kLdsStack : kLdsStackGroups) * kBlock];
+  DirectSource src; src.C = C; src.hits0 = hits0; src.scene = &S; src.anyhit = (any_blocker && (S.flags & 2u)) ? 1u : 0u;
+  src.set_layout(nls, nslots);
+  const uint32_t n = ((nslots + 63u) & ~63u) * nls;
+  constexpr int kTop = kRefill ? kTopGroupsRefill : kTopGroups;
+  __shared__ uint4 lds_top[kTop > 0 ? 4 * kTop : 1];
+  const TopLevels<kTop> top = load_top_levels<kTop>(S, lds_top);
+  __shared__ uint32_t lds_ctr;
+  const Work work = make_work(n, grab, &lds_ctr);
+  if constexpr (kRefill) {
+    __shared__ uint32_t lds_wbuf[(kBlock / 64) * kWbufWords * 64];
+    trace_wave<Tri>(S, top, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), tri_min, hits);
+  } else {
+    trace_wave_groups<Tri>(S, top, src, work, make_stack<kLdsStackGroups>(lds_stack, ovf), hits);
+  }
+}
+__global__ void k_store_camera(DevCamera C, DevCamera* dst) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = C;
 }
 
 // The inverse of the tiled-compact layout: parts[p][k * ts * ts + (y % ts) * ts + (x % ts)][c] of every
@@ -1424,80 +1482,111 @@ __device__ __forceinline__ bool can_see_light(const DevScene& S, V3 light, V3 P,
 
 // The local (non-recursive) part of Flyscene::calculateColor (src/flyscene.cpp:671-745) summed
 // over the light samples as Flyscene::Shader does (:611-626), times the node's throughput.
+// (h: the node's index in the lists that hang off it -- shadow hits, GI probes; i: the node)
+__device__ __forceinline__ void resolve_node(const PipeArgs& A, uint32_t h, uint32_t i, uint32_t NLS) {
+  const RayRec r = load_node(A, i);
+  const uint2 hh = A.hits[i];
+  const Surface sf = surface_of(A.S, r.o, r.d1, __uint_as_float(hh.x), (int)hh.y);
+  const DevMat mat = material_of(A.S, sf.mat);
+  const float I = 0.8f / (float)(A.S.nlights + A.S.nsl);
+  const V3 Iv = v3(I, I, I);
+  const V3 ka = v3(mat.ka[0], mat.ka[1], mat.ka[2]);
+  // global illumination term (src/flyscene.cpp:704-721), the same for every light
+  V3 gi = v3(0, 0, 0);
+  if (A.gi_rays > 0) {
+    for (int k = 0; k < A.gi_rays; ++k) {
+      const uint2 g = A.gi_hits[(size_t)h * (uint32_t)A.gi_rays + (uint32_t)k];
+      const float dist = __uint_as_float(g.x);
+      if (dist != 0.0f) {
+        const DevMat gm = material_of(A.S, (int)g.y);
+        const float fd = 50.0f * dist;
+        const double w = 1.0 / ((double)fd * (double)fd);
+        const float wf = (w < 1.0) ? (float)w : 1.0f;
+        gi = gi + v3(gm.kd[0] * wf, gm.kd[1] * wf, gm.kd[2] * wf);
+      }
+    }
+    gi = gi / (float)A.gi_rays;
+  }
+  V3 total = v3(0, 0, 0);
+  const V3 eye = normalized(r.o - sf.P);
+  for (uint32_t ls = 0; ls < NLS; ++ls) {
+    bool fifth;
+    const V3 light = light_sample(A, sf.P, ls, &fifth);
+    const V3 lightDir = normalized(light - sf.P);
+    const V3 reflectedLight = reflect_dir(-lightDir, sf.N);
+    const float dotted = dot(eye, normalized(reflectedLight));
+    bool visible = true; int bmat = -1;
+    if (A.shadows) {
+      // (the shadow ray's direction: the expression QueueSource formed it with, from the same light and point)
+      const uint2 sh = A.shadow_hits[shadow_index(h, ls, NLS)];
+      visible = can_see_light(A.S, light, sf.P, normalized(normalized(light - sf.P)), __uint_as_float(sh.x), (int)sh.y, &bmat);
+    }
+    const float ndl = dot(sf.N, lightDir);
+    const float md = (ndl < 0.0f) ? 0.0f : ndl;          // std::max(a, b) = (a < b) ? b : a
+    const float mdot = (dotted < 0.0f) ? 0.0f : dotted;
+    V3 c;
+    if (visible) {
+      const V3 ambient = cmul(ka, Iv);
+      const V3 diffuse = md * cmul(v3(mat.kd[0], mat.kd[1], mat.kd[2]), Iv);
+      // std::pow(float, 33) (src/flyscene.cpp:729): evaluated in double like libstdc++ does, by
+      // repeated squaring (x^32 * x) instead of the generic pow -- a few double ulps apart at
+      // most, far inside the 1e-4 RGB tolerance, and ~20x fewer instructions
+      const double xd = (double)mdot;
+      const double x2 = xd * xd, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8;
+      const float sp = (float)((x16 * x16) * xd);
+      const V3 specular = cmul(Iv, v3(mat.ks[0], mat.ks[1], mat.ks[2])) * sp;
+      c = ((ambient + diffuse) + specular) + gi;
+    } else {
+      const DevMat bm = (bmat == -1) ? default_mtl() : material_of(A.S, bmat);
+      const V3 ambientS = cmul(v3(bm.ka[0], bm.ka[1], bm.ka[2]), Iv);
+      const V3 diffuseS = md * cmul(v3(bm.kd[0], bm.kd[1], bm.kd[2]), Iv);
+      const float spS = powf(mdot, bm.ns);
+      const V3 specularS = cmul(Iv, v3(bm.ks[0], bm.ks[1], bm.ks[2])) * spS;
+      const V3 colorS = (ambientS + diffuseS) + specularS;
+      c = cmul(ka, Iv) + colorS * bm.d;
+    }
+    total = total + (fifth ? c / 5.0f : c);
+  }
+  float* px = A.rgb + 3 * (size_t)r.pixel;
+  const V3 add = v3(r.thr * total.x, r.thr * total.y, r.thr * total.z);
+  if (A.atomic_accum) { acc_add(A, r.pixel, 0, add.x); acc_add(A, r.pixel, 1, add.y); acc_add(A, r.pixel, 2, add.z); }
+  else if (A.first_gen) { px[0] = 0.0f + add.x; px[1] = 0.0f + add.y; px[2] = 0.0f + add.z; }      // the pixel's first node: traceRay's sum starts at zero
+  else { px[0] += add.x; px[1] += add.y; px[2] += add.z; }
+}
 __global__ __launch_bounds__(kBlock) void k_resolve(PipeArgs A) {
   const uint32_t n = A.counters[0];
   const uint32_t NLS = light_samples(A.S);
-  for (uint32_t h = blockIdx.x * kBlock + threadIdx.x; h < n; h += gridDim.x * kBlock) {
-    const uint32_t i = A.parents[h];
-    const RayRec r = load_node(A, i);
+  for (uint32_t h = blockIdx.x * kBlock + threadIdx.x; h < n; h += gridDim.x * kBlock) resolve_node(A, h, A.parents[h], NLS);
+}
+// The same for a camera frame without a parent list (run_pipeline's direct mode): every output slot of the call -- dead slots
+// skipped, a miss gets traceRay's miss colour (src/flyscene.cpp:596-600), a hit is its own parent (its shadow hits lie at
+// shadow_index(slot, ls)); out_t / out_face as k_shade writes them; counters[0] = the number of hits (ray statistics).
+__global__ __launch_bounds__(kBlock) void k_resolve_direct(PipeArgs A) {
+  __shared__ uint32_t s_hits;
+  if (threadIdx.x == 0) s_hits = 0;
+  __syncthreads();
+  const uint32_t NLS = light_samples(A.S);
+  uint32_t mine = 0;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < A.n0; i += gridDim.x * kBlock) {
+    uint32_t f; int x, y;
+    if (!slot_pixel(A.C, i, &f, &x, &y)) continue;
     const uint2 hh = A.hits[i];
-    const Surface sf = surface_of(A.S, r.o, r.d1, __uint_as_float(hh.x), (int)hh.y);
-    const DevMat mat = material_of(A.S, sf.mat);
-    const float I = 0.8f / (float)(A.S.nlights + A.S.nsl);
-    const V3 Iv = v3(I, I, I);
-    const V3 ka = v3(mat.ka[0], mat.ka[1], mat.ka[2]);
-    // global illumination term (src/flyscene.cpp:704-721), the same for every light
-    V3 gi = v3(0, 0, 0);
-    if (A.gi_rays > 0) {
-      for (int k = 0; k < A.gi_rays; ++k) {
-        const uint2 g = A.gi_hits[(size_t)h * (uint32_t)A.gi_rays + (uint32_t)k];
-        const float dist = __uint_as_float(g.x);
-        if (dist != 0.0f) {
-          const DevMat gm = material_of(A.S, (int)g.y);
-          const float fd = 50.0f * dist;
-          const double w = 1.0 / ((double)fd * (double)fd);
-          const float wf = (w < 1.0) ? (float)w : 1.0f;
-          gi = gi + v3(gm.kd[0] * wf, gm.kd[1] * wf, gm.kd[2] * wf);
-        }
-      }
-      gi = gi / (float)A.gi_rays;
+    const int id = (int)hh.y;
+    if (A.out_t) A.out_t[i] = __uint_as_float(hh.x);
+    if (A.out_face) A.out_face[i] = id >= 0 ? id : -1;
+    if (id == -1) {
+      const bool sky = A.bounce == 0;
+      float* px = A.rgb + 3 * (size_t)i;
+      px[0] = sky ? (float)0.69019607843 : 0.0f; px[1] = sky ? 1.0f : 0.0f; px[2] = sky ? 1.0f : 0.0f;
+      continue;
     }
-    V3 total = v3(0, 0, 0);
-    const V3 eye = normalized(r.o - sf.P);
-    for (uint32_t ls = 0; ls < NLS; ++ls) {
-      bool fifth;
-      const V3 light = light_sample(A, sf.P, ls, &fifth);
-      const V3 lightDir = normalized(light - sf.P);
-      const V3 reflectedLight = reflect_dir(-lightDir, sf.N);
-      const float dotted = dot(eye, normalized(reflectedLight));
-      bool visible = true; int bmat = -1;
-      if (A.shadows) {
-        // (the shadow ray's direction: the expression QueueSource formed it with, from the same light and point)
-        const uint2 sh = A.shadow_hits[shadow_index(h, ls, NLS)];
-        visible = can_see_light(A.S, light, sf.P, normalized(normalized(light - sf.P)), __uint_as_float(sh.x), (int)sh.y, &bmat);
-      }
-      const float ndl = dot(sf.N, lightDir);
-      const float md = (ndl < 0.0f) ? 0.0f : ndl;          // std::max(a, b) = (a < b) ? b : a
-      const float mdot = (dotted < 0.0f) ? 0.0f : dotted;
-      V3 c;
-      if (visible) {
-        const V3 ambient = cmul(ka, Iv);
-        const V3 diffuse = md * cmul(v3(mat.kd[0], mat.kd[1], mat.kd[2]), Iv);
-        // std::pow(float, 33) (src/flyscene.cpp:729): evaluated in double like libstdc++ does, by
-        // repeated squaring (x^32 * x) instead of the generic pow -- a few double ulps apart at
-        // most, far inside the 1e-4 RGB tolerance, and ~20x fewer instructions
-        const double xd = (double)mdot;
-        const double x2 = xd * xd, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8;
-        const float sp = (float)((x16 * x16) * xd);
-        const V3 specular = cmul(Iv, v3(mat.ks[0], mat.ks[1], mat.ks[2])) * sp;
-        c = ((ambient + diffuse) + specular) + gi;
-      } else {
-        const DevMat bm = (bmat == -1) ? default_mtl() : material_of(A.S, bmat);
-        const V3 ambientS = cmul(v3(bm.ka[0], bm.ka[1], bm.ka[2]), Iv);
-        const V3 diffuseS = md * cmul(v3(bm.kd[0], bm.kd[1], bm.kd[2]), Iv);
-        const float spS = powf(mdot, bm.ns);
-        const V3 specularS = cmul(Iv, v3(bm.ks[0], bm.ks[1], bm.ks[2])) * spS;
-        const V3 colorS = (ambientS + diffuseS) + specularS;
-        c = cmul(ka, Iv) + colorS * bm.d;
-      }
-      total = total + (fifth ? c / 5.0f : c);
-    }
-    float* px = A.rgb + 3 * (size_t)r.pixel;
-    const V3 add = v3(r.thr * total.x, r.thr * total.y, r.thr * total.z);
-    if (A.atomic_accum) { acc_add(A, r.pixel, 0, add.x); acc_add(A, r.pixel, 1, add.y); acc_add(A, r.pixel, 2, add.z); }
-    else if (A.first_gen) { px[0] = 0.0f + add.x; px[1] = 0.0f + add.y; px[2] = 0.0f + add.z; }      // the pixel's first node: traceRay's sum starts at zero
-    else { px[0] += add.x; px[1] += add.y; px[2] += add.z; }
+    ++mine;
+    resolve_node(A, i, i, NLS);
   }
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_hits, mine);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_hits) atomicAdd(&A.counters[0], s_hits);
 }
 
 // The fixed-point sums of a ray-tree call -> the caller's float pixels (slots of partial edge tiles stay untouched).
