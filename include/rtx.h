@@ -91,6 +91,10 @@ typedef struct {
   uint32_t nslots;    /* non-empty node slots; nnodes counts all 32-byte slots (4 per group) */
   uint32_t ntop_groups;   /* groups 0 .. ntop_groups-1 are the top three levels of the hierarchy, numbered breadth first
                              (the group-by-group traversal kernels keep them in LDS); deeper groups follow depth first */
+  uint32_t build_kind;    /* 0: the host's binned-SAH build; 1: built on the GPU (RTX_FLAG_DEVICE_BUILD) */
+  float device_build_ms;  /* wall time of the last build on the GPU (upload of the mesh included), 0 if none */
+  float refit_ms;         /* wall time of the last refit (rtx_scene_update_vertices), 0 if none */
+  uint32_t refits;        /* refits since the hierarchy's topology was built */
 } rtx_scene_info;
 
 const char* rtx_last_error(void);
@@ -145,6 +149,16 @@ int rtx_scene_set_lights(rtx_scene*, const float* xyz, uint32_t n, const float* 
  * the output slots, no compacted parent list is made.  With this flag such frames take the general path (parent list, one
  * hit-point record per parent), as frames with child rays always do; the two give the same pixels bit for bit (tested). */
 #define RTX_FLAG_PARENT_LIST 64u
+/* RTX_FLAG_DEVICE_BUILD (takes effect at the next rtx_scene_commit of a scene not built yet): the acceleration structure
+ * that replaces Box(mesh) + divideBox_KD (src/box.h:41-85, src/flyscene.cpp:77-82,1110-1185) is built ON THE GPU instead
+ * of on the host -- per-triangle records and padded boxes in the reference's arithmetic, Morton order, a binary radix
+ * tree, 4-wide groups chosen by the same expected-cost programme as the host's collapse (a few milliseconds per million
+ * triangles against 0.3 s for the host's binned-SAH build; DESIGN.md 5 has the traversal speed of either tree).  Results
+ * do not depend on the hierarchy: hits are a (t, face id) minimum over everything a ray can reach, whichever builder made
+ * the boxes (tested against the oracle both ways).  Meshes of fewer than 8 regular triangles, and trees too deep for the
+ * traversal stack, take the host builder all the same (rtx_scene_info.build_kind says which ran).
+ * RTX_BUILD=device|host in the environment overrides the flag (A/B runs). */
+#define RTX_FLAG_DEVICE_BUILD 128u
 int rtx_scene_set_flags(rtx_scene*, uint32_t flags);
 
 /* Flyscene::divideBox_KD + averagePoint / axisToDivide / isInBox and Box(mesh)
@@ -168,6 +182,22 @@ int rtx_scene_get_leafboxes(const rtx_scene*, float* bmin_xyz, float* bmax_xyz, 
  * and uploads everything to `device`. */
 int rtx_scene_build(rtx_scene*);
 int rtx_scene_commit(rtx_scene*, int device);
+/* New vertex positions for a committed scene (same vertex count, same triangles): an animated mesh.  The reference has
+ * no counterpart -- its mesh is loaded once and Box(mesh) / divideBox_KD run once in Flyscene::initialize
+ * (src/flyscene.cpp:22-23,77-82) -- but everything it derives from the vertices is derived again here, in its
+ * arithmetic: face normals, the per-triangle constants of Triangle::intersects, the root box of the root gate.
+ *   RTX_UPDATE_REFIT    keeps the hierarchy's topology and refits its boxes on the GPU, level by level from the leaves
+ *                       (tens of microseconds per level; the right choice while the mesh deforms smoothly);
+ *   RTX_UPDATE_REBUILD  builds the hierarchy again: on the GPU when the scene has RTX_FLAG_DEVICE_BUILD, else on the host.
+ * A refit that finds a triangle of the hierarchy degenerated into one whose accepted set no box can bound (DESIGN.md 3,
+ * "wild" triangles) rebuilds instead.  Hits after either are what a fresh scene with the new vertices gives, bit for bit.
+ * The reference leaf list of the GI probes (rtx_scene_build_reference_leafboxes) is a function of the vertices and is
+ * dropped: build it again if gi_rays > 0 is wanted.  Finishes the scene's enqueued renders first.
+ * rtx_scene_update_vertices takes a host pointer, rtx_scene_update_vertices_dev a device pointer on the scene's device. */
+#define RTX_UPDATE_REFIT 0
+#define RTX_UPDATE_REBUILD 1
+int rtx_scene_update_vertices(rtx_scene*, const float* verts_xyz, uint32_t nverts, int32_t how);
+int rtx_scene_update_vertices_dev(rtx_scene*, const float* verts_xyz, uint32_t nverts, int32_t how);
 int rtx_scene_get_info(const rtx_scene*, rtx_scene_info*);
 /* Host copy of the flattened acceleration structure (tests / roofline accounting).
  * nodes: nnodes x 8 words {lo.xyz, ref, hi.xyz, count}, in groups of 4 siblings (128 bytes); group 0

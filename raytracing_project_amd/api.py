@@ -42,7 +42,8 @@ class SceneInfo(C.Structure):
     _fields_ = [("ntris", C.c_uint32), ("nverts", C.c_uint32), ("nnodes", C.c_uint32), ("nleaves", C.c_uint32),
                 ("max_depth", C.c_uint32), ("nspheres", C.c_uint32), ("nlights", C.c_uint32),
                 ("nmaterials", C.c_uint32), ("device_bytes", C.c_uint64), ("build_ms", C.c_float),
-                ("nwild", C.c_uint32), ("nslots", C.c_uint32), ("ntop_groups", C.c_uint32)]
+                ("nwild", C.c_uint32), ("nslots", C.c_uint32), ("ntop_groups", C.c_uint32),
+                ("build_kind", C.c_uint32), ("device_build_ms", C.c_float), ("refit_ms", C.c_float), ("refits", C.c_uint32)]
 
 
 # every symbol include/rtx.h declares
@@ -54,11 +55,13 @@ SYMBOLS = ["rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_
            "rtx_get_stats", "rtx_scene_build_reference_leafboxes", "rtx_scene_set_leafboxes",
            "rtx_scene_get_leafboxes", "rtx_intersect_box", "rtx_trace_shade", "rtx_camera_points", "rtx_scene_set_flags",
            "rtx_scene_get_packed_bvh", "rtx_debug_hit", "rtx_trace_closest_noalloc", "rtx_scene_clone", "rtx_render_multi",
-           "rtx_render_multi_dev", "rtx_intersect_primitive", "rtx_trace_gi"]
+           "rtx_render_multi_dev", "rtx_intersect_primitive", "rtx_trace_gi", "rtx_scene_update_vertices", "rtx_scene_update_vertices_dev"]
 
 MAX_BATCH = 64
 NOALLOC_MAX_RAYS = 65536
 FLAG_NO_ROOT_GATE, FLAG_SCHED_REFILL, FLAG_SCHED_GROUPS, FLAG_SCHED_SPLIT, FLAG_VERIFY, FLAG_FAST_TRIANGLES, FLAG_PARENT_LIST = 1, 2, 4, 8, 16, 32, 64
+FLAG_DEVICE_BUILD = 128
+UPDATE_REFIT, UPDATE_REBUILD = 0, 1
 
 _lib = None
 
@@ -127,6 +130,8 @@ def lib():
         L.rtx_trace_shade.argtypes = [C.c_void_p, C.POINTER(Options), _f, _f, C.c_uint32, C.c_int32, C.c_int32, _f]
         L.rtx_camera_points.argtypes = [C.c_void_p, C.POINTER(Camera), _f, C.c_uint32, _f, _f]
         L.rtx_scene_set_flags.argtypes = [C.c_void_p, C.c_uint32]
+        L.rtx_scene_update_vertices.argtypes = [C.c_void_p, _f, C.c_uint32, C.c_int32]
+        L.rtx_scene_update_vertices_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32]
         L.rtx_scene_get_packed_bvh.argtypes = [C.c_void_p, _u]
         L.rtx_debug_hit.argtypes = [C.c_void_p, _f, _f, C.c_uint32, _f, C.POINTER(C.c_int32), _f, _f, C.POINTER(C.c_uint8)]
         L.rtx_tiles_count.argtypes = [Rect, C.c_int32, C.c_int32, C.c_int32]
@@ -275,6 +280,16 @@ class Scene:
 
     def commit(self, device=0):
         _check(lib().rtx_scene_commit(self.h, device))
+
+    def update_vertices(self, verts, how=UPDATE_REFIT):
+        """rtx_scene_update_vertices (host array) / rtx_scene_update_vertices_dev (a torch tensor on the scene's device)."""
+        if hasattr(verts, "data_ptr"):
+            assert verts.is_cuda and verts.is_contiguous() and verts.numel() == self.verts.size
+            _check(lib().rtx_scene_update_vertices_dev(self.h, verts.data_ptr(), len(self.verts), how))
+            return
+        v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
+        _check(lib().rtx_scene_update_vertices(self.h, fp(v), len(v), how))
+        self.verts = v
 
     def info(self):
         i = SceneInfo()

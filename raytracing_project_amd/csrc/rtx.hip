@@ -16,6 +16,7 @@
 #include "../../include/rtx.h"
 #include "bvh_build.h"
 #include "rtx_kernels.h"
+#include "bvh_device.h"
 
 using namespace rtx;
 static_assert(kStackDepth == kTraversalStackDepth, "the builder's depth fallback and the kernels' stack must agree");
@@ -98,6 +99,19 @@ struct rtx_scene {
   DevScene dev{};
   DevBuf d_nodes, d_tris, d_tris_mt, d_tri_face, d_face_nm, d_spheres, d_sph_mat, d_mats, d_lights;
   DevBuf d_slights, d_leafboxes, d_leaf_faces, d_face_pos;
+  // The hierarchy built / refitted on the GPU (bvh_device.h; RTX_FLAG_DEVICE_BUILD, rtx_scene_update_vertices).
+  bool geom_dev = false;               // d_nodes / d_tris / d_tri_face / d_face_nm / d_face_pos hold the current mesh on `device`
+  bool device_built = false;           // ... and the hierarchy among them was built on the GPU
+  bool host_stale = false;             // h_tri_leaf / h_tri_face / h_face_nm / bvh.quads / bvh.order are behind the device's state
+  bool verts_stale = false;            // `verts` is behind d_verts (rtx_scene_update_vertices_dev)
+  bool mesh_dev = false;               // d_verts / d_idx / d_tri_mat hold the mesh
+  bool refit_ready = false;            // d_quads / d_tri_box / the level lists match d_nodes
+  bool keep_build_ws = false;          // keep the build's temporaries (a caller that rebuilds per frame)
+  DevBuf d_verts, d_idx, d_tri_mat, d_quads, d_tri_box, d_level_groups, d_hdr;
+  std::vector<uint32_t> level_start;   // groups of level l: d_level_groups[level_start[l] .. level_start[l + 1]) -- or, for a tree built
+  bool level_identity = false;         // on the GPU (level_identity), that range of group indices itself
+  DevBuf b_keys[2], b_vals, b_sort_tmp, b_lr, b_par_int, b_par_leaf, b_arrived, b_list[2], b_bin[3], b_queue[2], b_nodes, b_quads;
+  float device_build_ms = 0.0f, refit_ms = 0.0f;
   // Workspace of one call: its streams and every buffer its kernels write.  Two of them (one per call slot,
   // below), so that two render calls can be in flight on the GPU at the same time: frame k+1's launches fill the
   // CUs that frame k's persistent traversal kernels leave free while their last waves drain.
@@ -201,7 +215,10 @@ extern "C" int rtx_scene_create(const float* verts, uint32_t nverts, const uint3
 static void release_device(rtx_scene* s) {
   if (s->device >= 0) (void)hipSetDevice(s->device);
   DevBuf* bufs[] = {&s->d_nodes, &s->d_tris, &s->d_tris_mt, &s->d_tri_face, &s->d_face_nm, &s->d_spheres, &s->d_sph_mat, &s->d_mats,
-                    &s->d_lights, &s->d_slights, &s->d_leafboxes, &s->d_leaf_faces, &s->d_face_pos};
+                    &s->d_lights, &s->d_slights, &s->d_leafboxes, &s->d_leaf_faces, &s->d_face_pos,
+                    &s->d_verts, &s->d_idx, &s->d_tri_mat, &s->d_quads, &s->d_tri_box, &s->d_level_groups, &s->d_hdr,
+                    &s->b_keys[0], &s->b_keys[1], &s->b_vals, &s->b_sort_tmp, &s->b_lr, &s->b_par_int, &s->b_par_leaf, &s->b_arrived,
+                    &s->b_list[0], &s->b_list[1], &s->b_bin[0], &s->b_bin[1], &s->b_bin[2], &s->b_queue[0], &s->b_queue[1], &s->b_nodes, &s->b_quads};
   for (rtx_scene::Slot& w : s->slots) {                        // calls still in flight
     if (w.stream) (void)hipStreamSynchronize(w.stream);
     if (w.stream2) (void)hipStreamSynchronize(w.stream2);
@@ -224,6 +241,7 @@ static void release_device(rtx_scene* s) {
     c.hc = nullptr; c.hc_words = 0; c.pending = false; c.unreported = false;
   }
   s->committed = false;
+  s->geom_dev = false; s->mesh_dev = false; s->refit_ready = false;
 }
 
 extern "C" int rtx_scene_destroy(rtx_scene* s) {
@@ -250,7 +268,7 @@ extern "C" int rtx_scene_set_spheres(rtx_scene* s, const float* cr4, const int32
 
 extern "C" int rtx_scene_set_flags(rtx_scene* s, uint32_t flags) {
   if (!s) return fail(RTX_EINVAL, "null scene");
-  if (flags & ~(uint32_t)(RTX_FLAG_NO_ROOT_GATE | RTX_FLAG_SCHED_REFILL | RTX_FLAG_SCHED_GROUPS | RTX_FLAG_SCHED_SPLIT | RTX_FLAG_VERIFY | RTX_FLAG_FAST_TRIANGLES | RTX_FLAG_PARENT_LIST))
+  if (flags & ~(uint32_t)(RTX_FLAG_NO_ROOT_GATE | RTX_FLAG_SCHED_REFILL | RTX_FLAG_SCHED_GROUPS | RTX_FLAG_SCHED_SPLIT | RTX_FLAG_VERIFY | RTX_FLAG_FAST_TRIANGLES | RTX_FLAG_PARENT_LIST | RTX_FLAG_DEVICE_BUILD))
     return fail(RTX_EINVAL, "unknown flag bits 0x%x", flags);
   if ((flags & RTX_FLAG_SCHED_REFILL) && (flags & RTX_FLAG_SCHED_GROUPS)) return fail(RTX_EINVAL, "pick one scheduler");
   if ((flags & RTX_FLAG_SCHED_SPLIT) && !(flags & RTX_FLAG_SCHED_REFILL)) return fail(RTX_EINVAL, "RTX_FLAG_SCHED_SPLIT modifies RTX_FLAG_SCHED_REFILL");
@@ -501,6 +519,238 @@ extern "C" int rtx_scene_build(rtx_scene* s) {
   return RTX_OK;
 }
 
+// ------------------------------------------------------------------ the hierarchy built / refitted on the GPU (bvh_device.h)
+static bool want_device_build(const rtx_scene* s) {
+  static const int env = [] { const char* e = std::getenv("RTX_BUILD"); return !e ? 0 : (std::strcmp(e, "device") == 0 ? 1 : (std::strcmp(e, "host") == 0 ? 2 : 0)); }();
+  if (env) return env == 1;
+  return (s->flags & RTX_FLAG_DEVICE_BUILD) != 0;
+}
+static double wild_below() { const char* e = std::getenv("RTX_WILD_BELOW"); const double v = e ? std::atof(e) : 0.0; return v > 0 ? v : 2.5e-6; }
+static float pad_scale() { const char* e = std::getenv("RTX_TEST_PAD_SCALE"); return e ? (float)std::atof(e) : 1.0f; }
+static int build_grid(size_t items) { return (int)std::max<size_t>(1, std::min<size_t>((items + 255) / 256, 4096)); }
+
+static int upload_mesh(rtx_scene* s, hipStream_t st) {
+  if (s->mesh_dev) return RTX_OK;
+  if (int rc = upload(s->d_verts, s->verts, st)) return rc;
+  if (int rc = upload(s->d_idx, s->idx, st)) return rc;
+  if (int rc = upload(s->d_tri_mat, s->tri_mat, st)) return rc;
+  s->mesh_dev = true;
+  return RTX_OK;
+}
+static void release_build_ws(rtx_scene* s) {
+  DevBuf* tmp[] = {&s->b_keys[0], &s->b_keys[1], &s->b_vals, &s->b_sort_tmp, &s->b_lr, &s->b_par_int, &s->b_par_leaf, &s->b_arrived,
+                   &s->b_list[0], &s->b_list[1], &s->b_bin[0], &s->b_bin[1], &s->b_bin[2], &s->b_queue[0], &s->b_queue[1], &s->b_nodes, &s->b_quads};
+  for (DevBuf* b : tmp) b->release();
+}
+// What the header's reductions say about the mesh as a whole: the root gate's box, the padding's validity range.
+static void take_bounds(rtx_scene* s, const devbuild::Header& H) {
+  for (int k = 0; k < 3; ++k) { s->root_lo[k] = devbuild::dec_f(H.root_lo[k]); s->root_hi[k] = devbuild::dec_f(H.root_hi[k]); }
+  float scene_abs; std::memcpy(&scene_abs, &H.abs_bits, 4);
+  s->domain = scene_abs > 0.0f ? 30.0f * scene_abs : INFINITY;
+}
+static int ensure_tri_buffers(rtx_scene* s, uint32_t ntris) {
+  if (int rc = s->d_tris.ensure((size_t)std::max<uint32_t>(ntris, 1) * 64)) return rc;
+  if (s->flags & RTX_FLAG_FAST_TRIANGLES) { if (int rc = s->d_tris_mt.ensure((size_t)std::max<uint32_t>(ntris, 1) * 48)) return rc; }
+  else s->d_tris_mt.release();
+  if (int rc = s->d_tri_face.ensure((size_t)std::max<uint32_t>(ntris, 1) * 4)) return rc;
+  if (int rc = s->d_face_nm.ensure((size_t)std::max<uint32_t>(ntris, 1) * 16)) return rc;
+  if (int rc = s->d_face_pos.ensure((size_t)std::max<uint32_t>(ntris, 1) * 4)) return rc;
+  if (int rc = s->d_tri_box.ensure((size_t)std::max<uint32_t>(ntris, 1) * 32)) return rc;
+  return RTX_OK;
+}
+// Returns RTX_OK with *fallback = true when the mesh is one the host builder has to take (too few regular triangles, a
+// tree too deep for the traversal stack).  The scene's device is current.
+static int device_build(rtx_scene* s, hipStream_t st, bool* fallback) {
+  using namespace devbuild;
+  *fallback = false;
+  const uint32_t ntris = (uint32_t)s->tri_mat.size(), nverts = (uint32_t)(s->verts.size() / 3);
+  if (ntris < 8) { *fallback = true; return RTX_OK; }
+  auto t0 = std::chrono::steady_clock::now();
+  if (int rc = upload_mesh(s, st)) return rc;
+  if (int rc = s->d_hdr.ensure(sizeof(Header))) return rc;
+  Header H; header_init(&H);
+  HIP_TRY(hipMemcpyAsync(s->d_hdr.p, &H, sizeof H, hipMemcpyHostToDevice, st));
+  Header* dH = s->d_hdr.as<Header>();
+  const float ps = pad_scale(); const double wb = wild_below();
+  static const float tri_cost = [] { const char* e = std::getenv("RTX_LBVH_TRI_COST"); return e ? (float)std::atof(e) : 0.6f; }();
+  if (int rc = s->b_keys[0].ensure((size_t)ntris * 8)) return rc;
+  if (int rc = s->b_keys[1].ensure((size_t)ntris * 8)) return rc;
+  if (int rc = s->b_vals.ensure((size_t)ntris * 4)) return rc;
+  if (int rc = ensure_tri_buffers(s, ntris)) return rc;
+  hipLaunchKernelGGL(k_vert_bounds, dim3(build_grid(nverts)), dim3(256), 0, st, s->d_verts.as<float>(), nverts, dH);
+  hipLaunchKernelGGL(k_tri_keys, dim3(build_grid(ntris)), dim3(256), 0, st, s->d_verts.as<float>(), s->d_idx.as<uint32_t>(), ntris, dH, ps, wb,
+                     s->b_keys[0].as<uint64_t>(), s->b_vals.as<uint32_t>());
+  size_t tmp_bytes = 0;
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, s->b_keys[0].as<uint64_t>(), s->b_keys[1].as<uint64_t>(), s->b_vals.as<uint32_t>(),
+                                             s->d_tri_face.as<uint32_t>(), (int)ntris, 0, 64, st));
+  if (int rc = s->b_sort_tmp.ensure(std::max<size_t>(tmp_bytes, 16))) return rc;
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(s->b_sort_tmp.p, tmp_bytes, s->b_keys[0].as<uint64_t>(), s->b_keys[1].as<uint64_t>(), s->b_vals.as<uint32_t>(),
+                                             s->d_tri_face.as<uint32_t>(), (int)ntris, 0, 64, st));
+  HIP_TRY(hipMemcpyAsync(&H, s->d_hdr.p, sizeof H, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const uint32_t nwild = H.nwild, nreg = ntris - nwild;
+  if (nreg < 8) { *fallback = true; return RTX_OK; }
+  hipLaunchKernelGGL(k_tri_setup_leaf, dim3(build_grid(ntris)), dim3(256), 0, st, s->d_verts.as<float>(), s->d_idx.as<uint32_t>(), s->d_tri_mat.as<int>(),
+                     s->d_tri_face.as<int>(), ntris, nreg, dH, ps, wb, s->d_tris.as<float4>(), s->d_tris_mt.as<float4>(), s->d_face_nm.as<float4>(),
+                     s->d_face_pos.as<int>(), s->d_tri_box.as<float4>());
+  // binary radix tree over the nreg sorted keys
+  if (int rc = s->b_lr.ensure((size_t)nreg * 8)) return rc;
+  if (int rc = s->b_par_int.ensure((size_t)nreg * 4)) return rc;
+  if (int rc = s->b_par_leaf.ensure((size_t)nreg * 4)) return rc;
+  if (int rc = s->b_arrived.ensure((size_t)nreg * 4)) return rc;
+  for (DevBuf& b : s->b_list) if (int rc = b.ensure((size_t)nreg * 4)) return rc;
+  for (DevBuf& b : s->b_bin) if (int rc = b.ensure((size_t)nreg * 16)) return rc;
+  for (DevBuf& b : s->b_queue) if (int rc = b.ensure((size_t)nreg * 8)) return rc;
+  if (int rc = s->b_nodes.ensure((size_t)nreg * 64)) return rc;
+  if (int rc = s->b_quads.ensure((size_t)nreg * 128)) return rc;
+  hipLaunchKernelGGL(k_radix_tree, dim3(build_grid(nreg)), dim3(256), 0, st, s->b_keys[1].as<uint64_t>(), (int)nreg, s->b_lr.as<uint2>(),
+                     s->b_par_int.as<uint32_t>(), s->b_par_leaf.as<uint32_t>());
+  HIP_TRY(hipMemsetAsync(s->b_arrived.p, 0, (size_t)nreg * 4, st));
+  BinArrays B{s->b_bin[0].as<float4>(), s->b_bin[1].as<float4>(), s->b_bin[2].as<float4>(), s->b_lr.as<uint2>(), s->d_tri_box.as<float4>()};
+  hipLaunchKernelGGL(k_bu_leaves, dim3(build_grid(nreg)), dim3(256), 0, st, nreg, s->b_par_leaf.as<uint32_t>(), s->b_arrived.as<uint32_t>(),
+                     s->b_list[1].as<uint32_t>(), dH);
+  for (int r = 1; r < kMaxRounds; ++r) {
+    // (a round holds at most half the nodes of the one before in a balanced tree; the loop inside takes whatever there is)
+    const size_t guess = std::max<size_t>((size_t)nreg >> std::min(r, 12), 16384);
+    hipLaunchKernelGGL(k_bu_round, dim3(build_grid(guess)), dim3(256), 0, st, r, s->b_list[r & 1].as<uint32_t>(), s->b_list[(r + 1) & 1].as<uint32_t>(), B,
+                       s->b_par_int.as<uint32_t>(), s->b_arrived.as<uint32_t>(), dH, tri_cost);
+  }
+  // groups, top-down; the expected-cost plan first, two binary levels per group if that tree is too deep for the stack
+  for (int fixed = 0; fixed < 2; ++fixed) {
+    if (fixed) {
+      HIP_TRY(hipMemsetAsync((char*)s->d_hdr.p + offsetof(Header, ngroups), 0, offsetof(Header, round_count) - offsetof(Header, ngroups), st));
+    }
+    hipLaunchKernelGGL(k_emit_seed, dim3(1), dim3(64), 0, st, s->b_queue[0].as<uint2>(), dH);
+    for (int level = 0; level < kMaxLevels; ++level) {
+      const size_t guess = level < 8 ? (size_t)1 << (2 * level + 2) : nreg;
+      hipLaunchKernelGGL(k_emit_level, dim3(build_grid(std::min<size_t>(guess, nreg))), dim3(256), 0, st, level, s->b_queue[level & 1].as<uint2>(),
+                         s->b_queue[(level + 1) & 1].as<uint2>(), dH, B, tri_cost, fixed, s->b_quads.as<BvhNode>(), s->b_nodes.as<uint4>());
+    }
+    HIP_TRY(hipMemcpyAsync(&H, s->d_hdr.p, sizeof H, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    uint64_t done = 0;
+    for (int r = 1; r <= kMaxRounds; ++r) done += H.round_count[r];
+    if (done != (uint64_t)nreg - 1) { *fallback = true; return RTX_OK; }     // a binary tree taller than the rounds provided for
+    if (H.level_count[kMaxLevels] == 0) break;
+    if (fixed) { *fallback = true; return RTX_OK; }
+  }
+  const uint32_t ngroups = H.ngroups;
+  if (ngroups >= (1u << 26)) return fail(RTX_ELIMIT, "BVH has %u node groups, the device encoding holds fewer than 2^26", ngroups);
+  // exact-size homes for what stays (the build's buffers are sized for the worst case, one group per triangle)
+  if (int rc = s->d_nodes.ensure((size_t)ngroups * 64)) return rc;
+  if (int rc = s->d_quads.ensure((size_t)ngroups * 128)) return rc;
+  HIP_TRY(hipMemcpyAsync(s->d_nodes.p, s->b_nodes.p, (size_t)ngroups * 64, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(s->d_quads.p, s->b_quads.p, (size_t)ngroups * 128, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  take_bounds(s, H);
+  s->nwild = nwild;
+  s->level_start.assign(1, 0);
+  uint32_t depth = 0;
+  for (int l = 0; l < kMaxLevels && H.level_count[l]; ++l) { s->level_start.push_back(s->level_start.back() + H.level_count[l]); ++depth; }
+  s->level_identity = true; s->refit_ready = true;
+  s->bvh = BvhBuildResult();
+  s->bvh.quad_depth = depth; s->bvh.quad_slots = H.nslots; s->bvh.nleaves = H.nleaves;
+  for (int l = 1; l <= kTopLevels; ++l) s->bvh.top_groups[l] = s->level_start[std::min<size_t>(l, s->level_start.size() - 1)];
+  auto t1 = std::chrono::steady_clock::now();
+  s->device_build_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+  rtx_scene_info& in = s->info;
+  std::memset(&in, 0, sizeof in);
+  in.ntris = ntris; in.nverts = nverts; in.nnodes = ngroups * 4; in.nleaves = H.nleaves; in.max_depth = depth; in.nwild = nwild;
+  in.nslots = H.nslots; in.ntop_groups = s->bvh.top_groups[kTopLevels]; in.build_ms = s->device_build_ms;
+  in.build_kind = 1; in.device_build_ms = s->device_build_ms;
+  s->built = true; s->geom_dev = true; s->device_built = true; s->host_stale = true;
+  if (!s->keep_build_ws) release_build_ws(s);
+  return RTX_OK;
+}
+
+// Host-built trees: what a refit needs beside the packed groups -- the fp32 slots and the groups of every level.
+static int refit_prepare(rtx_scene* s, hipStream_t st) {
+  if (s->refit_ready) return RTX_OK;
+  const uint32_t ntris = (uint32_t)s->tri_mat.size();
+  if (int rc = upload_mesh(s, st)) return rc;
+  if (int rc = upload(s->d_quads, s->bvh.quads, st)) return rc;
+  if (int rc = s->d_tri_box.ensure((size_t)std::max<uint32_t>(ntris, 1) * 32)) return rc;
+  if (int rc = s->d_hdr.ensure(sizeof(devbuild::Header))) return rc;
+  const uint32_t ngroups = (uint32_t)(s->bvh.quads.size() / 4);
+  std::vector<uint32_t> order; order.reserve(ngroups);
+  s->level_start.assign(1, 0);
+  std::vector<uint32_t> cur{0}, next;
+  while (!cur.empty()) {
+    next.clear();
+    for (uint32_t g : cur) {
+      order.push_back(g);
+      for (int k = 0; k < 4; ++k) {
+        const BvhNode& n = s->bvh.quads[4 * (size_t)g + k];
+        if (n.count == 0 && n.leftFirst != kEmptySlot) next.push_back(n.leftFirst);
+      }
+    }
+    s->level_start.push_back((uint32_t)order.size());
+    cur.swap(next);
+  }
+  if (int rc = upload(s->d_level_groups, order, st)) return rc;
+  HIP_TRY(hipStreamSynchronize(st));
+  s->level_identity = false; s->refit_ready = true;
+  return RTX_OK;
+}
+// New vertices are in d_verts: records, boxes, groups.  *rebuild = true when the topology cannot hold the new mesh.
+static int device_refit(rtx_scene* s, hipStream_t st, bool* rebuild) {
+  using namespace devbuild;
+  *rebuild = false;
+  const uint32_t ntris = (uint32_t)s->tri_mat.size(), nverts = (uint32_t)(s->verts.size() / 3);
+  if (int rc = refit_prepare(s, st)) return rc;
+  if (int rc = ensure_tri_buffers(s, ntris)) return rc;
+  Header H; header_init(&H);
+  HIP_TRY(hipMemcpyAsync(s->d_hdr.p, &H, sizeof H, hipMemcpyHostToDevice, st));
+  Header* dH = s->d_hdr.as<Header>();
+  hipLaunchKernelGGL(k_vert_bounds, dim3(build_grid(nverts)), dim3(256), 0, st, s->d_verts.as<float>(), nverts, dH);
+  hipLaunchKernelGGL(k_tri_setup_leaf, dim3(build_grid(ntris)), dim3(256), 0, st, s->d_verts.as<float>(), s->d_idx.as<uint32_t>(), s->d_tri_mat.as<int>(),
+                     s->d_tri_face.as<int>(), ntris, ntris - s->nwild, dH, pad_scale(), wild_below(), s->d_tris.as<float4>(), s->d_tris_mt.as<float4>(),
+                     s->d_face_nm.as<float4>(), s->d_face_pos.as<int>(), s->d_tri_box.as<float4>());
+  if (ntris - s->nwild > 0)
+    for (size_t l = s->level_start.size() - 1; l-- > 0;) {
+      const uint32_t base = s->level_start[l], count = s->level_start[l + 1] - base;
+      if (!count) continue;
+      hipLaunchKernelGGL(k_refit_level, dim3(build_grid(count)), dim3(256), 0, st, s->level_identity ? nullptr : s->d_level_groups.as<uint32_t>(), base,
+                         count, s->d_quads.as<BvhNode>(), s->d_tri_box.as<float4>(), s->d_nodes.as<uint4>());
+    }
+  HIP_TRY(hipMemcpyAsync(&H, s->d_hdr.p, sizeof H, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (H.wild_changed) { *rebuild = true; return RTX_OK; }
+  take_bounds(s, H);
+  s->host_stale = true;
+  return RTX_OK;
+}
+
+// Host copies of what the GPU built or refitted, for the exports (rtx_scene_get_*), rtx_scene_clone and a commit on another device.
+static int fetch_host_mirror(rtx_scene* s) {
+  if (!s->host_stale) return RTX_OK;
+  if (s->device < 0 || !s->geom_dev) return fail(RTX_ESTATE, "the scene's device state is gone");
+  HIP_TRY(hipSetDevice(s->device));
+  const uint32_t ntris = (uint32_t)s->tri_mat.size();
+  const uint32_t ngroups = s->info.nnodes / 4;
+  for (rtx_scene::Slot& w : s->slots) if (w.stream) HIP_TRY(hipStreamSynchronize(w.stream));      // (non-blocking streams: a plain copy does not wait for them)
+  if (s->verts_stale) { HIP_TRY(hipMemcpy(s->verts.data(), s->d_verts.p, s->verts.size() * 4, hipMemcpyDeviceToHost)); s->verts_stale = false; }
+  s->bvh.quads.resize((size_t)ngroups * 4);
+  HIP_TRY(hipMemcpy(s->bvh.quads.data(), s->d_quads.p, (size_t)ngroups * 128, hipMemcpyDeviceToHost));
+  s->h_tri_face.resize(std::max<uint32_t>(ntris, 1));
+  HIP_TRY(hipMemcpy(s->h_tri_face.data(), s->d_tri_face.p, (size_t)ntris * 4, hipMemcpyDeviceToHost));
+  s->bvh.order.assign(s->h_tri_face.begin(), s->h_tri_face.begin() + ntris);
+  s->h_face_nm.resize(std::max<uint32_t>(ntris, 1));
+  HIP_TRY(hipMemcpy(s->h_face_nm.data(), s->d_face_nm.p, (size_t)ntris * 16, hipMemcpyDeviceToHost));
+  std::vector<float4> dt((size_t)ntris * 4);
+  HIP_TRY(hipMemcpy(dt.data(), s->d_tris.p, (size_t)ntris * 64, hipMemcpyDeviceToHost));
+  s->h_tri_leaf.resize((size_t)ntris * 4);
+  for (size_t k = 0; k + 3 < dt.size(); k += 4) {       // device order {n, D} {v0, vv} {u, uu} {v, uv} -> export order {v0, D} {u, uu} {v, uv} {n, vv}
+    const float4 n = dt[k], a = dt[k + 1];
+    s->h_tri_leaf[k] = make_float4(a.x, a.y, a.z, n.w);
+    s->h_tri_leaf[k + 1] = dt[k + 2];
+    s->h_tri_leaf[k + 2] = dt[k + 3];
+    s->h_tri_leaf[k + 3] = make_float4(n.x, n.y, n.z, a.w);
+  }
+  s->host_stale = false;
+  return RTX_OK;
+}
+
 extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   if (!s) return fail(RTX_EINVAL, "null scene");
   int ndev = 0;
@@ -510,6 +760,8 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
     (void)hipSetDevice(s->device);
     for (rtx_scene::Call& c : s->calls) if (int rc = finish_call(s, c)) return rc;
   }
+  // what the GPU built or refitted comes to the host before its device copy may go (another device takes it from there)
+  if (s->host_stale && s->device >= 0 && s->device != device) if (int rc = fetch_host_mirror(s)) return rc;
   if (s->device >= 0 && s->device != device) release_device(s);
   HIP_TRY(hipSetDevice(device));
   s->device = device;
@@ -523,6 +775,17 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   s->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  // (the 48-byte records of RTX_FLAG_FAST_TRIANGLES come or go: the geometry is uploaded again, from the host copies)
+  if (s->geom_dev && ((s->flags & RTX_FLAG_FAST_TRIANGLES) != 0) != (s->d_tris_mt.p != nullptr)) {
+    if (int rc = fetch_host_mirror(s)) return rc;
+    HIP_TRY(hipSetDevice(device));
+    s->geom_dev = false;
+  }
+  if (!s->built && want_device_build(s)) {
+    bool fallback = false;
+    if (int rc = device_build(s, ws(s).stream, &fallback)) return rc;
+    if (fallback) { s->geom_dev = false; s->device_built = false; release_build_ws(s); }
+  }
   if (int rc = rtx_scene_build(s)) return rc;
   for (rtx_scene::Slot& w : s->slots) {
     if (int rc = w.w_stack_ovf.ensure((size_t)trace_grid(s) * kBlock * (kStackDepth - kLdsStack) * 4)) return rc;
@@ -548,6 +811,8 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   std::vector<int32_t> dsm = s->sph_mat; if (dsm.empty()) dsm.push_back(-1);
   // Device encoding of the groups: 64-byte PackedGroup (bvh_build.h); the exported layout of
   // rtx_scene_get_bvh stays the fp32 one {lo, ref, hi, count}.
+  const bool up_geom = !s->geom_dev;         // (a hierarchy the GPU built or refitted for this mesh is already where it belongs)
+  if (up_geom) {
   std::vector<PackedGroup> dnodes;
   pack_groups(s->bvh.quads, &dnodes);
   if (int rc = upload(s->d_nodes, dnodes, ws(s).stream)) return rc;
@@ -582,6 +847,8 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   }
   if (int rc = upload(s->d_tri_face, tri_face, ws(s).stream)) return rc;
   if (int rc = upload(s->d_face_nm, face_nm, ws(s).stream)) return rc;
+  s->refit_ready = false;                    // d_quads / the level lists belong to whatever tree was here before
+  }
   if (int rc = upload(s->d_spheres, ds, ws(s).stream)) return rc;
   if (int rc = upload(s->d_sph_mat, dsm, ws(s).stream)) return rc;
   if (int rc = upload(s->d_mats, dm, ws(s).stream)) return rc;
@@ -596,12 +863,16 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
     dlb[2 * i + 1] = make_float4(s->leaf_hi[3 * i], s->leaf_hi[3 * i + 1], s->leaf_hi[3 * i + 2], cw);
   }
   std::vector<int32_t> dlf = s->leaf_faces; if (dlf.empty()) dlf.push_back(0);
-  std::vector<int32_t> fpos(std::max<uint32_t>(ntris, 1), 0);
-  for (uint32_t k = 0; k < ntris; ++k) fpos[(size_t)tri_face[k]] = (int32_t)k;
   if (int rc = upload(s->d_slights, dsl, ws(s).stream)) return rc;
   if (int rc = upload(s->d_leafboxes, dlb, ws(s).stream)) return rc;
   if (int rc = upload(s->d_leaf_faces, dlf, ws(s).stream)) return rc;
-  if (int rc = upload(s->d_face_pos, fpos, ws(s).stream)) return rc;
+  if (up_geom) {
+    std::vector<int32_t> fpos(std::max<uint32_t>(ntris, 1), 0);
+    for (uint32_t k = 0; k < ntris; ++k) fpos[(size_t)tri_face[k]] = (int32_t)k;
+    if (int rc = upload(s->d_face_pos, fpos, ws(s).stream)) return rc;
+    HIP_TRY(hipStreamSynchronize(ws(s).stream));
+    s->geom_dev = true;
+  }
   HIP_TRY(hipStreamSynchronize(ws(s).stream));
 
   DevScene& d = s->dev;
@@ -654,22 +925,80 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   in.nspheres = d.nspheres; in.nlights = d.nlights; in.nmaterials = d.nmats;
   in.device_bytes = s->d_nodes.cap + s->d_tris.cap + s->d_tris_mt.cap + s->d_tri_face.cap + s->d_face_nm.cap + s->d_spheres.cap +
                     s->d_sph_mat.cap + s->d_mats.cap + s->d_lights.cap + s->d_slights.cap + s->d_leafboxes.cap +
-                    s->d_leaf_faces.cap + s->d_face_pos.cap;
+                    s->d_leaf_faces.cap + s->d_face_pos.cap;      // (what the traversal and shading kernels read; a refit's fp32 slots,
+                                                                 //  boxes and mesh copy -- d_quads, d_tri_box, d_verts ... -- come on top)
   for (auto& per_kind : s->tune) for (rtx_scene::Tune& T : per_kind) T = rtx_scene::Tune();     // another scene on this handle: the tuner starts over
   s->committed = true;
   return RTX_OK;
 }
 
+// ------------------------------------------------------------------ animated meshes
+static int update_vertices(rtx_scene* s, const float* verts, uint32_t nverts, int32_t how, bool on_device) {
+  if (!s || !verts) return fail(RTX_EINVAL, "null argument");
+  if (!s->committed || s->device < 0) return fail(RTX_ESTATE, "scene not committed");
+  if ((size_t)nverts * 3 != s->verts.size()) return fail(RTX_EINVAL, "the scene has %zu vertices, got %u", s->verts.size() / 3, nverts);
+  if (how != RTX_UPDATE_REFIT && how != RTX_UPDATE_REBUILD) return fail(RTX_EINVAL, "how must be RTX_UPDATE_REFIT or RTX_UPDATE_REBUILD");
+  HIP_TRY(hipSetDevice(s->device));
+  for (rtx_scene::Call& c : s->calls) if (int rc = finish_call(s, c)) return rc;
+  auto t0 = std::chrono::steady_clock::now();
+  hipStream_t st = ws(s).stream;
+  // a refit needs the old tree's fp32 slots: take them (host-built trees) before anything of the old state goes
+  if (how == RTX_UPDATE_REFIT) if (int rc = refit_prepare(s, st)) return rc;
+  if (int rc = upload_mesh(s, st)) return rc;
+  if (on_device) {
+    HIP_TRY(hipMemcpyAsync(s->d_verts.p, verts, (size_t)nverts * 12, hipMemcpyDeviceToDevice, st));
+    s->verts_stale = true;
+  } else {
+    std::memcpy(s->verts.data(), verts, (size_t)nverts * 12);
+    HIP_TRY(hipMemcpyAsync(s->d_verts.p, s->verts.data(), (size_t)nverts * 12, hipMemcpyHostToDevice, st));
+    s->verts_stale = false;
+  }
+  // Flyscene's leaf list `boxes` is made from the vertices (divideBox_KD): it does not describe the new mesh
+  s->have_leaves = false; s->leaf_lo.clear(); s->leaf_hi.clear(); s->leaf_start.clear(); s->leaf_count.clear(); s->leaf_faces.clear();
+  s->dev.nleafboxes = 0;
+  bool rebuild = how == RTX_UPDATE_REBUILD;
+  if (!rebuild) {
+    if (int rc = device_refit(s, st, &rebuild)) return rc;
+    if (!rebuild) ++s->info.refits;
+  }
+  if (rebuild) {
+    bool fallback = !want_device_build(s);
+    if (!fallback) {
+      s->keep_build_ws = true;
+      if (int rc = device_build(s, st, &fallback)) return rc;
+    }
+    if (fallback) {                  // the host's builder, from the host's copy of the vertices, and everything uploaded again
+      HIP_TRY(hipStreamSynchronize(st));      // (the copy into d_verts runs on a non-blocking stream)
+      if (s->verts_stale) { HIP_TRY(hipMemcpy(s->verts.data(), s->d_verts.p, s->verts.size() * 4, hipMemcpyDeviceToHost)); s->verts_stale = false; }
+      s->built = false; s->geom_dev = false; s->device_built = false; s->host_stale = false; s->refit_ready = false;
+      if (int rc = rtx_scene_commit(s, s->device)) return rc;
+    }
+  }
+  DevScene& d = s->dev;
+  d.nodes = s->d_nodes.as<uint4>(); d.tris = s->d_tris.as<float4>(); d.tris_mt = s->d_tris_mt.as<float4>(); d.tri_face = s->d_tri_face.as<int>();
+  d.face_nm = s->d_face_nm.as<float4>(); d.face_pos = s->d_face_pos.as<int>();
+  d.nwild = s->nwild; d.ntop = s->bvh.top_groups[kTopLevels];
+  for (int k = 0; k < 3; ++k) { d.root_lo[k] = s->root_lo[k]; d.root_hi[k] = s->root_hi[k]; }
+  auto t1 = std::chrono::steady_clock::now();
+  const float ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+  if (rebuild) s->info.refits = 0; else s->refit_ms = ms;
+  return RTX_OK;
+}
+extern "C" int rtx_scene_update_vertices(rtx_scene* s, const float* verts, uint32_t nverts, int32_t how) { return update_vertices(s, verts, nverts, how, false); }
+extern "C" int rtx_scene_update_vertices_dev(rtx_scene* s, const float* verts, uint32_t nverts, int32_t how) { return update_vertices(s, verts, nverts, how, true); }
+
 extern "C" int rtx_scene_get_info(const rtx_scene* s, rtx_scene_info* out) {
   if (!s || !out) return fail(RTX_EINVAL, "null argument");
   if (!s->built) return fail(RTX_ESTATE, "scene not built (rtx_scene_build / rtx_scene_commit)");
   *out = s->info;
+  out->device_build_ms = s->device_build_ms; out->refit_ms = s->refit_ms;
   return RTX_OK;
 }
 
 extern "C" int rtx_scene_get_tris(const rtx_scene* s, float* tri16) {
   if (!s || !tri16) return fail(RTX_EINVAL, "null argument");
   if (!s->built) return fail(RTX_ESTATE, "scene not built (rtx_scene_build / rtx_scene_commit)");
+  if (int rc = fetch_host_mirror(const_cast<rtx_scene*>(s))) return rc;      // (a hierarchy the GPU built or refitted: copied back on demand)
   std::memcpy(tri16, s->h_tri_leaf.data(), s->h_tri_leaf.size() * sizeof(float4));
   return RTX_OK;
 }
@@ -677,6 +1006,7 @@ extern "C" int rtx_scene_get_tris(const rtx_scene* s, float* tri16) {
 extern "C" int rtx_scene_get_bvh(const rtx_scene* s, uint32_t* nodes8, uint32_t* tri_face) {
   if (!s) return fail(RTX_EINVAL, "null scene");
   if (!s->built) return fail(RTX_ESTATE, "scene not built (rtx_scene_build / rtx_scene_commit)");
+  if (int rc = fetch_host_mirror(const_cast<rtx_scene*>(s))) return rc;      // (a hierarchy the GPU built or refitted: copied back on demand)
   if (nodes8) std::memcpy(nodes8, s->bvh.quads.data(), s->bvh.quads.size() * sizeof(BvhNode));
   if (tri_face) std::memcpy(tri_face, s->bvh.order.data(), s->bvh.order.size() * 4);
   return RTX_OK;
@@ -685,6 +1015,7 @@ extern "C" int rtx_scene_get_bvh(const rtx_scene* s, uint32_t* nodes8, uint32_t*
 extern "C" int rtx_scene_get_packed_bvh(const rtx_scene* s, uint32_t* groups16) {
   if (!s) return fail(RTX_EINVAL, "null scene");
   if (!s->built) return fail(RTX_ESTATE, "scene not built (rtx_scene_build / rtx_scene_commit)");
+  if (int rc = fetch_host_mirror(const_cast<rtx_scene*>(s))) return rc;      // (a hierarchy the GPU built or refitted: copied back on demand)
   if (!groups16) return fail(RTX_EINVAL, "null argument");
   std::vector<PackedGroup> g;
   pack_groups(s->bvh.quads, &g);
@@ -1840,6 +2171,7 @@ bool multi_self_test() {
 // on another device without flattening the mesh and building the BVH again.
 extern "C" int rtx_scene_clone(const rtx_scene* src, rtx_scene** out) {
   if (!src || !out) return fail(RTX_EINVAL, "null argument");
+  if (int rc = fetch_host_mirror(const_cast<rtx_scene*>(src))) return rc;      // (what the GPU built or refitted travels as its host copy)
   rtx_scene* s = new rtx_scene();
   s->verts = src->verts; s->idx = src->idx; s->tri_mat = src->tri_mat; s->mats = src->mats;
   s->spheres = src->spheres; s->sph_mat = src->sph_mat; s->lights = src->lights; s->slights = src->slights;
@@ -1848,6 +2180,7 @@ extern "C" int rtx_scene_clone(const rtx_scene* src, rtx_scene** out) {
   s->built = src->built; s->h_tri_leaf = src->h_tri_leaf; s->h_face_nm = src->h_face_nm; s->h_tri_face = src->h_tri_face;
   std::memcpy(s->root_lo, src->root_lo, sizeof s->root_lo); std::memcpy(s->root_hi, src->root_hi, sizeof s->root_hi);
   s->nwild = src->nwild; s->bvh = src->bvh; s->info = src->info; s->domain = src->domain;
+  s->device_build_ms = src->device_build_ms; s->refit_ms = src->refit_ms;
   *out = s;
   return RTX_OK;
 }

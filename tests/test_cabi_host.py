@@ -37,7 +37,7 @@ def test_struct_layouts_match_header(api):
     assert C.sizeof(api.Options) == 6 * 4
     assert C.sizeof(api.Rect) == 16
     assert C.sizeof(api.Stats) == 5 * 8 + 16 + 16        # + rays_out_of_domain, verify_checked, verify_mismatches (padded to 8)
-    assert C.sizeof(api.SceneInfo) == 8 * 4 + 8 + 4 + 4 + 4 + 4   # ..., build_ms, nwild, nslots, tail padding
+    assert C.sizeof(api.SceneInfo) == 8 * 4 + 8 + 4 + 4 + 4 + 4 + 4 * 4   # ..., build_ms, nwild, nslots, ntop_groups, build_kind, device_build_ms, refit_ms, refits
 
 
 def test_argument_validation(api):
