@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the single-frame and verification passes")
     ap.add_argument("--fast-triangles", action="store_true", help="RTX_FLAG_FAST_TRIANGLES: the watertight Moeller-Trumbore functor instead of the reference's "
                                                                   "arithmetic (hit ids no longer bit-exact; a measurement mode, never the headline)")
+    ap.add_argument("--device-build", action="store_true", help="RTX_FLAG_DEVICE_BUILD: the hierarchy built on the GPU (Morton-ordered LBVH) instead of the host's "
+                                                                "binned-SAH build; same hits, a measurement of the other tree")
     ap.add_argument("--static-camera", action="store_true", help="every frame from the same camera (rounds 1-2 measured that)")
     ap.add_argument("--out-format", default="rgb8", choices=["rgb8", "f32"],
                     help="what the ranks of an N > 1 run hand to rank 0: the P3 bytes of result.ppm (3 B/pixel) or the float frame (12)")
@@ -198,8 +200,9 @@ def main():
     W, H = wl["W"], wl["H"]
     scene = api.Scene(wl["verts"], wl["idx"], wl["tri_mat"], [api.make_material(**m) for m in wl["mats"]])
     scene.set_lights(wl["lights"])
-    if args.fast_triangles:
-        scene.set_flags(api.FLAG_FAST_TRIANGLES)
+    base_flags = (api.FLAG_FAST_TRIANGLES if args.fast_triangles else 0) | (api.FLAG_DEVICE_BUILD if args.device_build else 0)
+    if base_flags:
+        scene.set_flags(base_flags)
     scene.commit(local_rank)
     info = scene.info()
     opts = api.Options(*wl["opts"])
@@ -448,11 +451,11 @@ def main():
                   "note": "one frame per render call, one call at a time (host wait included): the latency of a single raytraceScene"}
         # The timed configuration once more with the standing check on: every camera launch re-checks ~2,000 of its rays by
         # brute force over every triangle (the reference's own algorithm); a mismatch would be a hit the hierarchy lost.
-        scene.set_flags(api.FLAG_VERIFY | (api.FLAG_FAST_TRIANGLES if args.fast_triangles else 0))
+        scene.set_flags(api.FLAG_VERIFY | base_flags)
         cams = [cams_of(f)[0] for f in range(B)]
         scene.render_tiles_batch_dev(cams, opts, rect, 0, 0, 1, sets[0]["rgb"].data_ptr(), None, sets[0]["face"].data_ptr())
         st = scene.stats()
-        scene.set_flags(api.FLAG_FAST_TRIANGLES if args.fast_triangles else 0)
+        scene.set_flags(base_flags)
         verify = {"checked": int(st.verify_checked), "mismatches": int(st.verify_mismatches), "rays_out_of_domain": int(st.rays_out_of_domain),
                   "note": "RTX_FLAG_VERIFY on one batch of %d frames: sampled camera rays re-traced by brute force over all triangles" % B}
     # pixels whose primary ray hit geometry, from the hit ids of the last frame on every rank
@@ -474,7 +477,9 @@ def main():
             "repeats": {"n": R, "reported": "median", "value": sorted(values), "ms_per_step": sorted(float(x) / args.steps * 1e3 for x in tmax),
                         "spread": (max(values) - min(values)) / float(np.median(values)) if R > 1 else 0.0},
             "config": {"workload": args.workload, "triangles": int(info.ntris), "bvh_nodes": int(info.nnodes),
-                       "bvh_build_ms_host": float(info.build_ms), "scene_device_bytes": int(info.device_bytes),
+                       "bvh_builder": "device: Morton-ordered radix tree, expected-cost collapse (RTX_FLAG_DEVICE_BUILD)" if info.build_kind else "host: binned SAH, 16 threads",
+                       "bvh_build_ms_host": None if info.build_kind else float(info.build_ms), "bvh_build_ms_device": float(info.device_build_ms) if info.build_kind else None,
+                       "bvh_group_levels": int(info.max_depth), "scene_device_bytes": int(info.device_bytes),
                        "triangles_outside_bvh": int(info.nwild),
                        "image": [W, H], "lights": len(wl["lights"]), "spp": wl["spp"], "max_bounces": wl["opts"][0],
                        "camera": "one fixed view" if args.static_camera else "a camera path: every frame from the next position of an orbit about the scene (%.2f degrees per frame)"
@@ -502,6 +507,8 @@ def main():
             result["single_frame"] = single
         if verify is not None:
             result["verify"] = verify
+    if rank == 0 and world == 1 and pipelined and not args.no_extras:
+        result["device_build"] = device_build_figures(api, torch, wl, scene, info, opts, rect, lambda k: cams_of(k)[0], sets[0])
     if rank == 0 and rehearse:
         result["config"]["rehearsal"] = True
         if pipelined:      # the reassembled parts against one full-frame render of the same camera, bit for bit
@@ -534,6 +541,55 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     scene.close()
+
+
+def device_build_figures(api, torch, wl, scene, info, opts, rect, cam_of, bufs):
+    """The hierarchy built / refitted on the GPU (RTX_FLAG_DEVICE_BUILD, rtx_scene_update_vertices_dev) on this workload's
+    mesh: wall times with the vertices already on the device, and an animated frame -- new vertices, refit, one render
+    call -- on a second handle of the scene (the timed scene above is left alone)."""
+    d = api.Scene(wl["verts"], wl["idx"], wl["tri_mat"], [api.make_material(**m) for m in wl["mats"]])
+    d.set_lights(wl["lights"])
+    d.set_flags(api.FLAG_DEVICE_BUILD)
+    d.commit(torch.cuda.current_device())
+    di = d.info()
+    v = torch.from_numpy(np.ascontiguousarray(wl["verts"], np.float32)).cuda()
+    amp = 1e-3 * float(np.abs(wl["verts"]).max())
+
+    def moved(k):          # the mesh of frame k: every vertex displaced a little along a travelling wave
+        return v + amp * torch.sin(v[:, [1, 2, 0]] * 3.0 + 0.37 * k)
+    def timed(how, n):
+        ts = []
+        for k in range(n):
+            nv = moved(k)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter(); d.update_vertices(nv, how); ts.append((time.perf_counter() - t0) * 1e3)
+        return float(np.median(ts[1:]))
+    rebuild = timed(api.UPDATE_REBUILD, 6)
+    refit = timed(api.UPDATE_REFIT, 8)
+    for k in range(10):   # the tuner's trials on this handle
+        d.render_tiles_batch_dev([cam_of(k)], opts, rect, 0, 0, 1, bufs["rgb"].data_ptr(), None, bufs["face"].data_ptr())
+    n = 24
+    rays = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(n):
+        nv = moved(k)
+        torch.cuda.synchronize()        # (the library's streams do not wait for torch's: the vertices have to be there, as for every _dev entry point)
+        d.update_vertices(nv, api.UPDATE_REFIT)
+        d.render_tiles_batch_dev([cam_of(k)], opts, rect, 0, 0, 1, bufs["rgb"].data_ptr(), None, bufs["face"].data_ptr())
+        st = d.stats()
+        rays += st.rays_primary + st.rays_shadow + st.rays_reflection
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"build_ms_first": float(di.device_build_ms), "rebuild_ms": rebuild, "refit_ms": refit, "host_build_ms": float(info.build_ms) if not info.build_kind else None,
+           "groups": int(di.nnodes // 4), "group_levels": int(di.max_depth), "built_on_device": bool(di.build_kind),
+           "animated_frame": {"ms_per_frame": dt / n * 1e3, "mrays_per_s": rays / dt / 1e6,
+                              "refits": int(d.info().refits),
+                              "note": "every frame: new vertex positions (a device tensor computed by torch), rtx_scene_update_vertices_dev(REFIT), one render call, one call at a time"},
+           "note": "Morton-ordered radix tree + expected-cost collapse built on the GPU, wall ms with the vertices resident (median; the first build also loads the sort's kernels); "
+                   "the timed scene above uses the %s tree" % ("device-built" if info.build_kind else "host's binned-SAH")}
+    d.close()
+    return out
 
 
 def scaling_proxy(scene, cam_of, opts, rect, W, H, torch, dev, tiles, inflight=2):

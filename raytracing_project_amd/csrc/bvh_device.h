@@ -80,14 +80,27 @@ __global__ __launch_bounds__(256) void k_vert_bounds(const float* __restrict__ v
       if (x > mx[k]) mx[k] = x;            // (a NaN fails both, as in the reference's loop)
       if (x < mn[k]) mn[k] = x;
     }
+  // 13 reductions: wave, then block through LDS, then one atomic per value and block (an atomic per WAVE on these few
+  // addresses, 200 k of them at 4096 blocks, took 2.4 ms of a 4 ms build)
   amax = wave_max(amax);
   for (int k = 0; k < 3; ++k) { mn[k] = wave_min(mn[k]); mx[k] = wave_max(mx[k]); flo[k] = wave_min(flo[k]); fhi[k] = wave_max(fhi[k]); }
+  __shared__ float red[4][13];
+  const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
-    atomicMax(&H->abs_bits, __float_as_uint(amax));
-    for (int k = 0; k < 3; ++k) {
-      atomicMin(&H->root_lo[k], enc_f(mn[k])); atomicMax(&H->root_hi[k], enc_f(mx[k]));
-      atomicMin(&H->fin_lo[k], enc_f(flo[k])); atomicMax(&H->fin_hi[k], enc_f(fhi[k]));
-    }
+    red[wave][0] = amax;
+    for (int k = 0; k < 3; ++k) { red[wave][1 + k] = mn[k]; red[wave][4 + k] = mx[k]; red[wave][7 + k] = flo[k]; red[wave][10 + k] = fhi[k]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 13) {
+    const int j = threadIdx.x;
+    const bool is_min = (j >= 1 && j <= 3) || (j >= 7 && j <= 9);
+    float v = red[0][j];
+    for (int w = 1; w < 4; ++w) v = is_min ? fminf(v, red[w][j]) : fmaxf(v, red[w][j]);
+    if (j == 0) atomicMax(&H->abs_bits, __float_as_uint(v));
+    else if (j <= 3) atomicMin(&H->root_lo[j - 1], enc_f(v));
+    else if (j <= 6) atomicMax(&H->root_hi[j - 4], enc_f(v));
+    else if (j <= 9) atomicMin(&H->fin_lo[j - 7], enc_f(v));
+    else atomicMax(&H->fin_hi[j - 10], enc_f(v));
   }
 }
 

@@ -509,6 +509,27 @@ class Flyscene {
     std::cout << "Time elapsed: " << (long)ms << " ms" << std::endl << "ray tracing done! " << std::endl;
   }
 
+  // A mesh that moves.  No counterpart in the reference, which loads its mesh once (src/flyscene.cpp:22-23) and builds
+  // Box(mesh) / divideBox_KD once (:77-82): new positions for the loaded vertices (same count, same faces); the
+  // hierarchy is refitted on the GPU (rtx_scene_update_vertices; rebuilt when `rebuild` is set or a face degenerates),
+  // the leaf list of the GI probes is split again from the new vertices as initialize would.
+  const std::vector<float>& getVertices() const { return mesh.verts; }
+  void updateVertices(const std::vector<float>& xyz, bool rebuild = false) {
+    std::lock_guard<std::recursive_mutex> guard(mu);
+    if (xyz.size() != mesh.verts.size()) throw RtxError(RTX_EINVAL, "updateVertices: the mesh has another number of vertices");
+    sync();
+    drop_replicas();
+    mesh.verts = xyz;
+    rtx_check(rtx_scene_update_vertices(scene, mesh.verts.data(), (uint32_t)(mesh.verts.size() / 3), rebuild ? RTX_UPDATE_REBUILD : RTX_UPDATE_REFIT));
+    boxes.clear();
+    if (options.gi_rays > 0) {
+      if (rtx_scene_build_reference_leafboxes(scene, 0, 0) < 0) { std::cerr << "warning: " << rtx_last_error() << "; global illumination probes disabled" << std::endl; options.gi_rays = 0; }
+      else fetch_boxes();
+    }
+    dirty = true;
+    sync();
+  }
+
   // How many scene handles render a frame (rtx_render_multi: part i of the tile grid on handle i, all at once):
   // 0 = one per visible GPU, the multi-GPU form of the reference's 16 threads (src/flyscene.cpp:417-430); 1 = a
   // single rtx_render.  Handles beyond the number of GPUs share devices (device = index modulo GPUs).

@@ -128,6 +128,30 @@ def main():
             if not (np.array_equal(vis, ovis) and np.array_equal(bm, obm)):
                 print("seed %d: canSeeLight differs on %d of %d points" % (seed, int(((vis != ovis) | (bm != obm)).sum()), len(hp)))
                 sys.exit(1)
+        # the mesh moves (rtx_scene_update_vertices: refit, now and then a rebuild; every few scenes a triangle is squeezed flat, which
+        # forces the rebuild): hits on the new vertices against a fresh oracle scene (RTX_FUZZ_REFIT=1; draws of their own, so that
+        # a seed's scene is the same with and without)
+        if os.environ.get("RTX_FUZZ_REFIT") == "1":
+            rng2 = np.random.default_rng(seed + 7777777)
+            fin = np.isfinite(T) & (np.abs(T) < 1e30)
+            ph = rng2.uniform(0, 6.28, 3); fr = rng2.uniform(0.5, 4.0, 3) / ext
+            T2 = T.astype(np.float64)
+            disp = 0.03 * ext * np.stack([np.sin(fr[0] * T2[..., 1] + ph[0]), np.cos(fr[1] * T2[..., 2] + ph[1]), np.sin(fr[2] * T2[..., 0] + ph[2])], -1)
+            T2 = np.where(fin, T2 + np.where(np.isfinite(disp), disp, 0.0), T2).astype(np.float32)
+            if rng2.random() < 0.3:
+                k = rng2.integers(0, len(T2), 3)
+                T2[k, 2] = T2[k, 0] + (T2[k, 1] - T2[k, 0]) * np.float32(0.5)
+            nv = T2.reshape(-1, 3)
+            s.update_vertices(nv, api.UPDATE_REBUILD if rng2.random() < 0.15 else api.UPDATE_REFIT)
+            nr = min(len(org), 100000)
+            t2, f2 = s.trace_closest(org[:nr], d[:nr])
+            h2 = oa.Scene(nv, idx, tri_mat, [oa.make_mtl(**m) for m in mats]).closest(org[:nr], d[:nr], threads=16)
+            bad2 = np.nonzero((f2 != h2["face"]) | (t2.view(np.uint32) != h2["t"].view(np.uint32)))[0]
+            if len(bad2):
+                i = bad2[0]
+                print("seed %d: after the vertex update %d of %d rays differ; first: ray %d gpu (%d, %r) oracle (%d, %r), refits %d" % (
+                    seed, len(bad2), nr, i, f2[i], t2[i], h2["face"][i], h2["t"][i], s.info().refits))
+                sys.exit(1)
         s.close()
         # ... and a small frame through the whole pipeline: camera rays, shadow rays (point and spherical lights),
         # reflection / refraction trees, spheres, GI probes over the reference's leaf list where that list exists

@@ -138,6 +138,19 @@ int main(int argc, char** argv) {
       try { fs.updating_pixels(bad, origin, size, 1, 0); std::printf("nonsquare accepted\n"); }
       catch (const RtxError&) { std::printf("nonsquare refused\n"); }
     }
+    // a mesh that moves: new vertex positions from the optional fourth file, refit on the GPU, the frame again on one handle
+    if (argc > 4) {
+      std::vector<float> nv;
+      std::ifstream vf(argv[4]);
+      float x;
+      while (vf >> x) nv.push_back(x);
+      fs.updateVertices(nv);
+      fs.render_parts = 1;
+      fs.markCameraChanged();
+      fs.raytraceScene(W2, H2);
+      std::rename("result.ppm", "result_moved.ppm");
+      std::printf("moved %zu boxes %zu\n", nv.size() / 3, fs.boxes.size());
+    }
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());
     return 1;

@@ -49,7 +49,14 @@ def test_facade_matches_oracle(tmp_path, oa):
         for o_, d_ in zip(org, d):
             f.write("%.9g %.9g %.9g %.9g %.9g %.9g\n" % (*o_, *d_))
     W = 48
-    out = subprocess.run([DEMO, base + ".obj", str(W), base + ".rays"], cwd=str(tmp_path), capture_output=True, text=True,
+    # the mesh of the last frame: every vertex moved a little (Flyscene::updateVertices -> rtx_scene_update_vertices, a refit)
+    moved = fx["verts"].astype(np.float32).copy()
+    moved[:, 1] += (np.float32(0.08) * np.sin(np.float32(3.0) * moved[:, 0])).astype(np.float32)
+    moved[:, 0] += np.float32(0.05)
+    with open(base + ".moved", "w") as f:
+        for v_ in moved:
+            f.write("%.9g %.9g %.9g\n" % tuple(v_))
+    out = subprocess.run([DEMO, base + ".obj", str(W), base + ".rays", base + ".moved"], cwd=str(tmp_path), capture_output=True, text=True,
                          timeout=300)
     assert out.returncode == 0, out.stderr
     lines = [l.split() for l in out.stdout.splitlines() if l.strip()]
@@ -165,3 +172,19 @@ def test_facade_matches_oracle(tmp_path, oa):
     w = np.array(want_txt[4:], np.int64)
     assert g.shape == w.shape and np.abs(g - w).max() <= 1 and (g != w).mean() < 0.01
     assert ["nonsquare", "refused"] in lines
+    # the moved mesh: the refitted scene's frame equals the oracle's on the new vertices (reference options: GI probes over the
+    # leaf list split again from the new vertices, spheres, refraction)
+    o2 = oa.Scene(moved, fx["idx"], fx["tri_mat"], oracle_materials(fx["mats"]))
+    o2.set_lights([[-1.0, 1.0, 1.0]])
+    nl2 = o2.build_leafboxes()
+    o2.set_options()
+    ids2 = [o2.add_material(oa.make_mtl(ka=tuple(ka[i]), kd=tuple(kd[i]), ks=(.5, .5, .5), ns=10, ni=1, d=0, illum=2)) for i in range(len(cr))]
+    o2.set_spheres(cr, ids2)
+    assert ["moved", str(len(moved)), "boxes", str(nl2)] in lines
+    want3, _, _ = o2.render(oa.make_camera(scenes.default_view(), W2, H2), (0, 0, W2, H2), threads=8, want_hits=False)
+    assert oa.lib().ora_ppm_write(str(tmp_path / "want_moved.ppm").encode(), oa.fp(want3), W2, H2, 0) == 0
+    got_txt, want_txt = open(tmp_path / "result_moved.ppm").read().split(), open(tmp_path / "want_moved.ppm").read().split()
+    g = np.array(got_txt[4:], np.int64)
+    w = np.array(want_txt[4:], np.int64)
+    assert g.shape == w.shape and np.abs(g - w).max() <= 1 and (g != w).mean() < 0.01
+    assert (w != np.array(open(tmp_path / "want_wide.ppm").read().split()[4:], np.int64)).mean() > 0.01     # (the mesh did move)
