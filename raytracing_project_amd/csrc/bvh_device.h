@@ -7,7 +7,7 @@
 // quality only, never in results (tests/test_gpu_device_build.py renders both against the oracle).
 //
 // Build: per-triangle records and padded boxes in the reference's arithmetic (the host's expressions, shared through
-// tri_setup below) -> 63-bit Morton keys of the box centres -> radix sort (rocPRIM through hipcub; not a hot-path kernel)
+// tri_setup below) -> 63-bit extended Morton keys of the boxes (centre and size) -> radix sort (rocPRIM through hipcub; not a hot-path kernel)
 // -> Karras' binary radix tree, one thread per inner node -> boxes, triangle counts and the collapse plan bottom-up ->
 // 4-wide groups top-down, written in the 64-byte packed encoding the traversal kernels load.
 // No data is handed from one workgroup to another INSIDE a launch: the bottom-up pass runs in rounds (a node is
@@ -172,8 +172,20 @@ __device__ __forceinline__ uint64_t spread21(uint32_t v) {
 
 // Mesh order: the sort key of every face (Morton code of its padded box's centre; all ones for a wild face, so that
 // the wild list is the tail of the leaf order, where the kernels expect it) and the face id as the value.
+// Extended Morton code (Vinkler, Bittner, Havran 2017): the size of the box is a fourth coordinate, interleaved with the
+// three of its centre -- x y z s, 16 + 16 + 16 + 15 bits -- so that a triangle much larger than its neighbours leaves
+// their subtree within the first few splits instead of sitting in a leaf among them and stretching every box above it
+// (the hall's twelve wall triangles among 262 k column facets: +5.5 %; soup and bunny unchanged).
+__device__ __forceinline__ uint64_t extended_key(const uint32_t q[3], uint32_t qs) {
+  uint64_t key = 0;
+  for (int i = 15; i >= 0; --i) {
+    key = key << 3 | (uint64_t)((q[0] >> i) & 1u) << 2 | (uint64_t)((q[1] >> i) & 1u) << 1 | (uint64_t)((q[2] >> i) & 1u);
+    if (i > 0) key = key << 1 | (uint64_t)((qs >> (i - 1)) & 1u);
+  }
+  return key;
+}
 __global__ __launch_bounds__(256) void k_tri_keys(const float* __restrict__ verts, const uint32_t* __restrict__ idx, uint32_t ntris, Header* H,
-                                                  float pad_scale, double wild_below, uint64_t* keys, uint32_t* vals) {
+                                                  float pad_scale, double wild_below, int extended, uint64_t* keys, uint32_t* vals) {
   const PadParams pp = pad_params(H, pad_scale, wild_below);
   float glo[3], gext[3];
   for (int k = 0; k < 3; ++k) { glo[k] = dec_f(H->fin_lo[k]); gext[k] = dec_f(H->fin_hi[k]) - glo[k]; }
@@ -189,6 +201,13 @@ __global__ __launch_bounds__(256) void k_tri_keys(const float* __restrict__ vert
         q[k] = (uint32_t)fmin(fmax(x, 0.0), 2097151.0);
       }
       key = spread21(q[0]) << 2 | spread21(q[1]) << 1 | spread21(q[2]);
+      if (extended) {
+        const float gmax = fmaxf(gext[0], fmaxf(gext[1], gext[2]));
+        const float ext = fmaxf(S.hi[0] - S.lo[0], fmaxf(S.hi[1] - S.lo[1], S.hi[2] - S.lo[2]));
+        const double xs = gmax > 0.0f ? (double)ext / (double)gmax * 32768.0 : 0.0;
+        const uint32_t q16[3] = {q[0] >> 5, q[1] >> 5, q[2] >> 5};
+        key = extended_key(q16, (uint32_t)fmin(fmax(xs, 0.0), 32767.0));
+      }
     } else {
       ++wild_here;
     }

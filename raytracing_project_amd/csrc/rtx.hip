@@ -575,12 +575,13 @@ static int device_build(rtx_scene* s, hipStream_t st, bool* fallback) {
   // a leaf slot's triangle test priced against a group step in the collapse plan (measured: 0.3 / 0.6 / 1.0 / 2.0 give the 1M soup
   // 6.1 / 7.2 / 7.5 / 7.5 Grays/s, the bunny 17.5 / 17.3 / 18.0 / 17.7; the hall does not care)
   static const float tri_cost = [] { const char* e = std::getenv("RTX_LBVH_TRI_COST"); return e ? (float)std::atof(e) : 1.0f; }();
+  static const int extended = [] { const char* e = std::getenv("RTX_LBVH_EXTENDED"); return e ? std::atoi(e) : 1; }();     // (A/B hook: 0 = plain Morton keys)
   if (int rc = s->b_keys[0].ensure((size_t)ntris * 8)) return rc;
   if (int rc = s->b_keys[1].ensure((size_t)ntris * 8)) return rc;
   if (int rc = s->b_vals.ensure((size_t)ntris * 4)) return rc;
   if (int rc = ensure_tri_buffers(s, ntris)) return rc;
   hipLaunchKernelGGL(k_vert_bounds, dim3(std::min(build_grid(nverts), 512)), dim3(256), 0, st, s->d_verts.as<float>(), nverts, dH);
-  hipLaunchKernelGGL(k_tri_keys, dim3(build_grid(ntris)), dim3(256), 0, st, s->d_verts.as<float>(), s->d_idx.as<uint32_t>(), ntris, dH, ps, wb,
+  hipLaunchKernelGGL(k_tri_keys, dim3(build_grid(ntris)), dim3(256), 0, st, s->d_verts.as<float>(), s->d_idx.as<uint32_t>(), ntris, dH, ps, wb, extended,
                      s->b_keys[0].as<uint64_t>(), s->b_vals.as<uint32_t>());
   size_t tmp_bytes = 0;
   HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, s->b_keys[0].as<uint64_t>(), s->b_keys[1].as<uint64_t>(), s->b_vals.as<uint32_t>(),
