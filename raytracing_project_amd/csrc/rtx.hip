@@ -945,6 +945,8 @@ static int update_vertices(rtx_scene* s, const float* verts, uint32_t nverts, in
   for (rtx_scene::Call& c : s->calls) if (int rc = finish_call(s, c)) return rc;
   auto t0 = std::chrono::steady_clock::now();
   hipStream_t st = ws(s).stream;
+  // (an error on the way leaves device buffers half written: the scene then counts as not committed, and says so, until a commit succeeds)
+  s->committed = false;
   // a refit needs the old tree's fp32 slots: take them (host-built trees) before anything of the old state goes
   if (how == RTX_UPDATE_REFIT) if (int rc = refit_prepare(s, st)) return rc;
   if (int rc = upload_mesh(s, st)) return rc;
@@ -985,6 +987,7 @@ static int update_vertices(rtx_scene* s, const float* verts, uint32_t nverts, in
   auto t1 = std::chrono::steady_clock::now();
   const float ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
   if (rebuild) s->info.refits = 0; else s->refit_ms = ms;
+  s->committed = true;
   return RTX_OK;
 }
 extern "C" int rtx_scene_update_vertices(rtx_scene* s, const float* verts, uint32_t nverts, int32_t how) { return update_vertices(s, verts, nverts, how, false); }

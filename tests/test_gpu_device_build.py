@@ -304,3 +304,29 @@ def test_hall_with_reflections_on_a_device_built_tree(api):
     cams = [api.make_camera(scenes.look_at_view((0, 1.5, 7.0), (0.5, 1.2, 0)), 320, 180)]
     same_frames(api, h, d, cams, (320, 180), bounces=3, what="hall")
     h.close(); d.close()
+
+
+@pytest.mark.parametrize("device_build", [False, True])
+def test_update_vertices_on_tiny_and_empty_meshes(api, oa, device_build):
+    """Meshes below the GPU builder's size (the host's builder takes them: a lone leaf group, or nothing) refit and rebuild as well."""
+    rng = np.random.default_rng(31)
+    for n in (0, 1, 4, 9):
+        T = rng.uniform(-1, 1, (n, 3, 3)).astype(np.float32)
+        verts = T.reshape(-1, 3) if n else np.zeros((3, 3), np.float32)
+        idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+        s = make(api, verts, idx, None, one_material(api), device_build)
+        assert s.info().build_kind == (1 if device_build and n >= 8 else 0)
+        org = rng.uniform(-2, 2, (4000, 3)).astype(np.float32)
+        d = rng.normal(size=(4000, 3)).astype(np.float32)
+        for how in (api.UPDATE_REFIT, api.UPDATE_REBUILD, api.UPDATE_REFIT):
+            verts = (verts + rng.uniform(-0.2, 0.2, verts.shape)).astype(np.float32)
+            s.update_vertices(verts, how)
+            t, face = s.trace_closest(org, d)
+            ref = oa.Scene(verts, idx, None, [oa.make_mtl()]).closest(org, d, threads=4)
+            assert np.array_equal(face, ref["face"])
+            assert_bits_equal(t, ref["t"], "t, %d triangles" % n)
+        with pytest.raises(api.RtxError):
+            s.update_vertices(np.zeros((len(verts) + 1, 3), np.float32))       # another vertex count is refused
+        t, face = s.trace_closest(org, d)                                         # ... and leaves the scene as it was
+        assert np.array_equal(face, ref["face"])
+        s.close()
