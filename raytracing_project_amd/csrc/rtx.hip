@@ -1311,6 +1311,7 @@ static int guard_camera(rtx_scene* s, const DevCamera& C, const DevCamera* cams,
   hipLaunchKernelGGL(k_guard_camera, dim3(grid), dim3(kBlock), 0, ws(s).stream, s->dev, C, nslots, s->domain, vs, hits, ws(s).w_guard.as<uint32_t>());
   return RTX_OK;
 }
+static bool any_unordered() { static const bool on = [] { const char* e = std::getenv("RTX_ANY_UNORDERED"); return !e || std::atoi(e) != 0; }(); return on; }
 static int launch_trace_camera(rtx_scene* s, const DevCamera& C, uint32_t tiles, uint2* hits) {
   const uint32_t grid = trace_blocks(s, tiles);
   const uint32_t grid_r = std::min<uint32_t>(grid, (uint32_t)s->ncu * RTX_BLOCKS_REFILL);
@@ -1337,13 +1338,17 @@ static int launch_trace_queue(rtx_scene* s, const float4* rays, const uint32_t* 
   const uint32_t bounded = shadow ? ((any_blocker ? 3u : 1u) | 4u | (compact ? 8u : 0u)) : 0u;      // 4: the queue is in shadow_index order; 8: one hit point per parent
   const bool fast = (s->flags & RTX_FLAG_FAST_TRIANGLES) != 0;
   const uint32_t tri_min = mode == SCHED_REFILL_SPLIT ? kTriMinSplit : 1u;
+  // every ray of the launch stops at its first hit: no child sort in its node steps (RTX_ANY_UNORDERED=0: the A/B switch)
+  const bool any = shadow && any_blocker && (s->dev.flags & 2u) && any_unordered();
+#define RTX_LAUNCH_Q(REFILL, TRI, G, TM) do { \
+    if (any) hipLaunchKernelGGL((k_trace_queue<REFILL, TRI, true>), dim3(G), dim3(kBlock), 0, on, s->dev, rays, count, stride, bounded, grab_size(), TM, ovf, hits); \
+    else hipLaunchKernelGGL((k_trace_queue<REFILL, TRI, false>), dim3(G), dim3(kBlock), 0, on, s->dev, rays, count, stride, bounded, grab_size(), TM, ovf, hits); } while (0)
   if (mode != SCHED_GROUPS) {
-    if (fast) hipLaunchKernelGGL((k_trace_queue<true, FastTri>), dim3(grid_r), dim3(kBlock), 0, on, s->dev, rays, count, stride, bounded, grab_size(), tri_min, ovf, hits);
-    else hipLaunchKernelGGL((k_trace_queue<true, RefTri>), dim3(grid_r), dim3(kBlock), 0, on, s->dev, rays, count, stride, bounded, grab_size(), tri_min, ovf, hits);
+    if (fast) RTX_LAUNCH_Q(true, FastTri, grid_r, tri_min); else RTX_LAUNCH_Q(true, RefTri, grid_r, tri_min);
   } else {
-    if (fast) hipLaunchKernelGGL((k_trace_queue<false, FastTri>), dim3(grid), dim3(kBlock), 0, on, s->dev, rays, count, stride, bounded, grab_size(), 1u, ovf, hits);
-    else hipLaunchKernelGGL((k_trace_queue<false, RefTri>), dim3(grid), dim3(kBlock), 0, on, s->dev, rays, count, stride, bounded, grab_size(), 1u, ovf, hits);
+    if (fast) RTX_LAUNCH_Q(false, FastTri, grid, 1u); else RTX_LAUNCH_Q(false, RefTri, grid, 1u);
   }
+#undef RTX_LAUNCH_Q
   return RTX_OK;
 }
 
@@ -1357,13 +1362,16 @@ static int launch_trace_shadow_direct(rtx_scene* s, const DevCamera* cam_dev, co
   const uint32_t tri_min = mode == SCHED_REFILL_SPLIT ? kTriMinSplit : 1u;
   uint32_t* ovf = ws(s).w_stack_ovf.as<uint32_t>();
   hipStream_t on = ws(s).stream;
+  const bool any = (s->dev.flags & 2u) && any_unordered();
+#define RTX_LAUNCH_D(REFILL, TRI, G, TM) do { \
+    if (any) hipLaunchKernelGGL((k_trace_shadow_direct<REFILL, TRI, true>), dim3(G), dim3(kBlock), 0, on, s->dev, cam_dev, hits0, nslots, nls, 1u, grab_size(), TM, ovf, hits); \
+    else hipLaunchKernelGGL((k_trace_shadow_direct<REFILL, TRI, false>), dim3(G), dim3(kBlock), 0, on, s->dev, cam_dev, hits0, nslots, nls, 1u, grab_size(), TM, ovf, hits); } while (0)
   if (mode != SCHED_GROUPS) {
-    if (fast) hipLaunchKernelGGL((k_trace_shadow_direct<true, FastTri>), dim3(grid_r), dim3(kBlock), 0, on, s->dev, cam_dev, hits0, nslots, nls, 1u, grab_size(), tri_min, ovf, hits);
-    else hipLaunchKernelGGL((k_trace_shadow_direct<true, RefTri>), dim3(grid_r), dim3(kBlock), 0, on, s->dev, cam_dev, hits0, nslots, nls, 1u, grab_size(), tri_min, ovf, hits);
+    if (fast) RTX_LAUNCH_D(true, FastTri, grid_r, tri_min); else RTX_LAUNCH_D(true, RefTri, grid_r, tri_min);
   } else {
-    if (fast) hipLaunchKernelGGL((k_trace_shadow_direct<false, FastTri>), dim3(grid), dim3(kBlock), 0, on, s->dev, cam_dev, hits0, nslots, nls, 1u, grab_size(), 1u, ovf, hits);
-    else hipLaunchKernelGGL((k_trace_shadow_direct<false, RefTri>), dim3(grid), dim3(kBlock), 0, on, s->dev, cam_dev, hits0, nslots, nls, 1u, grab_size(), 1u, ovf, hits);
+    if (fast) RTX_LAUNCH_D(false, FastTri, grid, 1u); else RTX_LAUNCH_D(false, RefTri, grid, 1u);
   }
+#undef RTX_LAUNCH_D
   return RTX_OK;
 }
 

@@ -420,7 +420,10 @@ __device__ __forceinline__ TopLevels<kTop> load_top_levels(const DevScene& S, ui
   }
   return T;
 }
-template <class StackT, class TopT>
+// kOrdered = false (rays whose first hit decides: the shadow rays of a scene where any blocker shades alike): the children a ray
+// enters are taken in slot order, without the sort -- which blocker such a ray finds does not show in the result, and a ray
+// that finds none walks the same boxes in any order.
+template <bool kOrdered, class StackT, class TopT>
 __device__ __forceinline__ bool node_step(const DevScene& S, const TopT& top, const StackT& stk, float lim, float ivx, float ivy, float ivz, float oix,
                                           float oiy, float oiz, uint32_t* cur, int* sp_io) {
   int sp = *sp_io;
@@ -479,6 +482,28 @@ __device__ __forceinline__ bool node_step(const DevScene& S, const TopT& top, co
       en[k + j] = ents[k + j];
       tn[k + j] = (n_ <= f_) ? n_ : INFINITY;
     }
+  }
+  if constexpr (!kOrdered) {
+    const bool h0 = tn[0] != INFINITY, h1 = tn[1] != INFINITY, h2 = tn[2] != INFINITY, h3 = tn[3] != INFINITY;
+    if (sp <= StackT::kLdsEntries - 4) {
+      // four unconditional LDS stores, the stack pointer advancing over the real ones; the last of them is taken at once
+      stk.lds[sp * kBlock] = en[0]; sp += h0 ? 1 : 0;
+      stk.lds[sp * kBlock] = en[1]; sp += h1 ? 1 : 0;
+      stk.lds[sp * kBlock] = en[2]; sp += h2 ? 1 : 0;
+      stk.lds[sp * kBlock] = en[3]; sp += h3 ? 1 : 0;
+      if (!(h0 || h1 || h2 || h3)) { *sp_io = sp; return false; }
+      --sp;
+    } else {
+      // (near the end of the LDS part: push all but the last hit, so that no more than three entries are added per level)
+      const int last = h3 ? 3 : h2 ? 2 : h1 ? 1 : h0 ? 0 : -1;
+      if (last < 0) { *sp_io = sp; return false; }
+      if (h0 && last != 0) { stk.push(sp, en[0]); ++sp; }
+      if (h1 && last != 1) { stk.push(sp, en[1]); ++sp; }
+      if (h2 && last != 2) { stk.push(sp, en[2]); ++sp; }
+    }
+    *sp_io = sp;
+    *cur = h3 ? en[3] : h2 ? en[2] : h1 ? en[1] : en[0];
+    return true;
   }
   // sort the 4 candidates near-to-far; misses carry tn = +inf.  The nearest and the farthest are exact
   // after four compare-exchanges; the order of the two in between only matters for efficiency (RTX_SORT_CX).
@@ -684,7 +709,7 @@ constexpr int kDeferMin = RTX_DEFER_MIN;
 constexpr int kBlockMin = RTX_BLOCK_MIN;
 constexpr int kWbufWords = 9;             // o.xyz, d.xyz, best.t, best.id, slot
 
-template <class Tri, class Source>
+template <class Tri, bool kOrdered, class Source>
 __device__ __forceinline__ void trace_wave(const DevScene& S, const TopLevels<kTopGroupsRefill>& top, const Source& src, Work work, const Stack<kLdsStack>& stk, lds_u32* wbuf,
                                            uint32_t tri_min, uint2* hits) {
   const uint32_t lane = threadIdx.x & 63;
@@ -779,7 +804,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& S, const TopLevels<kT
 #pragma unroll
     for (int rep = 1; rep < RTX_NODE_UNROLL; ++rep) {
       if (cur < kDone) {
-        bool p1 = !node_step(S, top, stk, best.t * kPruneSlack, ivx, ivy, ivz, oix, oiy, oiz, &cur, &sp);
+        bool p1 = !node_step<kOrdered>(S, top, stk, best.t * kPruneSlack, ivx, ivy, ivz, oix, oiy, oiz, &cur, &sp);
         if (RTX_SPEC != 0 && (RTX_SPEC == 1 || !src.first_hit_decides()) && (int)cur < 0 && pend == kDone) { pend = cur; p1 = true; }
         if (p1) { if (sp == 0) cur = kDone; else { --sp; cur = stk.pop(sp); } }
       }
@@ -792,7 +817,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& S, const TopLevels<kT
     const uint64_t node_mask = __ballot(at_node);
     bool pop = false;
     if (at_node) {
-      pop = !node_step(S, top, stk, best.t * kPruneSlack, ivx, ivy, ivz, oix, oiy, oiz, &cur, &sp);
+      pop = !node_step<kOrdered>(S, top, stk, best.t * kPruneSlack, ivx, ivy, ivz, oix, oiy, oiz, &cur, &sp);
     }
     if (leaf_mask != 0 && (node_mask == 0 || __popcll(leaf_mask) >= kDeferMin || __popcll(leaf_mask & ~node_mask) >= kBlockMin)) {
       // One triangle per lane and pass; passes go on while at least tri_min lanes still have
@@ -825,7 +850,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& S, const TopLevels<kT
 // bookkeeping per step, which wins where the rays of a group stay in step (coherent rays on
 // closed surfaces); the refilling scheduler above wins on incoherent work (triangle soups,
 // diffuse bounces).
-template <class Tri, class Source>
+template <class Tri, bool kOrdered, class Source>
 __device__ __forceinline__ void trace_wave_groups(const DevScene& S, const TopLevels<kTopGroups>& top, const Source& src, Work work, const Stack<kLdsStackGroups>& stk,
                                                   uint2* hits) {
   const uint32_t lane = threadIdx.x & 63;
@@ -858,7 +883,7 @@ __device__ __forceinline__ void trace_wave_groups(const DevScene& S, const TopLe
         int sp = 0;
         for (;;) {
           if ((int)cur >= 0) {
-            if (node_step(S, top, stk, best.t * kPruneSlack, ivx, ivy, ivz, oix, oiy, oiz, &cur, &sp)) continue;
+            if (node_step<kOrdered>(S, top, stk, best.t * kPruneSlack, ivx, ivy, ivz, oix, oiy, oiz, &cur, &sp)) continue;
           } else {
             const uint32_t first = cur & 0x0FFFFFFFu, cnt = (cur >> 28) & 7u;
             for (uint32_t k = first; k < first + cnt; ++k) Tri::test(S, k, o, d, &best);
@@ -972,14 +997,16 @@ __global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_tra
   const Work work = make_work(nblocks * (uint32_t)kBlock, grab, &lds_ctr);
   if constexpr (kRefill) {
     __shared__ uint32_t lds_wbuf[(kBlock / 64) * kWbufWords * 64];
-    trace_wave<Tri>(S, top, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), tri_min, hits);
+    trace_wave<Tri, true>(S, top, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), tri_min, hits);
   } else {
-    trace_wave_groups<Tri>(S, top, src, work, make_stack<kLdsStackGroups>(lds_stack, ovf), hits);
+    trace_wave_groups<Tri, true>(S, top, src, work, make_stack<kLdsStackGroups>(lds_stack, ovf), hits);
   }
 }
 
 // Queued rays: rays[2i] = {o.xyz, aux}, rays[2i+1] = {d1.xyz, aux}; *count * stride rays.
-template <bool kRefill, class Tri = RefTri>
+// kAnyOrder: the launch's rays all stop at their first hit (the host says so: a shadow queue of a scene where any blocker shades alike);
+// their node steps then skip the child sort.
+template <bool kRefill, class Tri = RefTri, bool kAnyOrder = false>
 __global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_trace_queue(DevScene S, const float4* rays, const uint32_t* count, uint32_t stride,
                                                          uint32_t bounded, uint32_t grab, uint32_t tri_min, uint32_t* ovf, uint2* hits) {
   __shared__ uint32_t lds_stack[(kRefill ? kLdsStack : kLdsStackGroups) * kBlock];
@@ -995,14 +1022,14 @@ __global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_tra
   const Work work = make_work(n, grab, &lds_ctr);
   if constexpr (kRefill) {
     __shared__ uint32_t lds_wbuf[(kBlock / 64) * kWbufWords * 64];
-    trace_wave<Tri>(S, top, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), tri_min, hits);
+    trace_wave<Tri, !kAnyOrder>(S, top, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), tri_min, hits);
   } else {
-    trace_wave_groups<Tri>(S, top, src, work, make_stack<kLdsStackGroups>(lds_stack, ovf), hits);
+    trace_wave_groups<Tri, !kAnyOrder>(S, top, src, work, make_stack<kLdsStackGroups>(lds_stack, ovf), hits);
   }
 }
 
 // Shadow rays of a camera frame straight from its hit records (DirectSource): nslots output slots x nls light samples.
-template <bool kRefill, class Tri = RefTri>
+template <bool kRefill, class Tri = RefTri, bool kAnyOrder = false>
 __global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_trace_shadow_direct(DevScene S, const DevCamera* C, const uint2* hits0, uint32_t nslots,
                                                          uint32_t nls, uint32_t any_blocker, uint32_t grab, uint32_t tri_min, uint32_t* ovf, uint2* hits) {
   __shared__ uint32_t lds_stack[(kRefill ? kLdsStack : kLdsStackGroups) * kBlock];
@@ -1016,9 +1043,9 @@ __global__ __launch_bounds__(kBlock, kRefill ? RTX_BLOCKS_REFILL : 8) void k_tra
   const Work work = make_work(n, grab, &lds_ctr);
   if constexpr (kRefill) {
     __shared__ uint32_t lds_wbuf[(kBlock / 64) * kWbufWords * 64];
-    trace_wave<Tri>(S, top, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), tri_min, hits);
+    trace_wave<Tri, !kAnyOrder>(S, top, src, work, make_stack<kLdsStack>(lds_stack, ovf), (lds_u32*)lds_wbuf + (threadIdx.x >> 6) * (kWbufWords * 64), tri_min, hits);
   } else {
-    trace_wave_groups<Tri>(S, top, src, work, make_stack<kLdsStackGroups>(lds_stack, ovf), hits);
+    trace_wave_groups<Tri, !kAnyOrder>(S, top, src, work, make_stack<kLdsStackGroups>(lds_stack, ovf), hits);
   }
 }
 __global__ void k_store_camera(DevCamera C, DevCamera* dst) {
