@@ -748,7 +748,11 @@ def roofline(args, wl, scene, info, ms, rays, frames_per_launch=1, views=None):
         per_ray.update({"shadow_nodes": float(nv2.mean()), "shadow_tris": float(tt2.mean()),
                         "shadow_rays_stop_at_any_blocker": bool(anyhit)})
     spp = wl["spp"]
-    cand = [("k_trace_camera", prim_bytes * B, prim_layout * B, ms[0] / spp * B), ("k_trace_queue", sh_bytes * B, sh_layout * B, ms[1] / spp * B)]
+    # (a frame without child rays takes the library's direct mode: its shadow launch is k_trace_shadow_direct)
+    o_ = wl["opts"]
+    direct = (o_[0] == 0 or (o_[1] == 0 and o_[2] == 0)) and o_[3] == 0 and os.environ.get("RTX_DIRECT", "1") != "0"
+    cand = [("k_trace_camera", prim_bytes * B, prim_layout * B, ms[0] / spp * B),
+            ("k_trace_shadow_direct" if direct else "k_trace_queue", sh_bytes * B, sh_layout * B, ms[1] / spp * B)]
     if wl["opts"][0] > 0:     # reflection launches share k_trace_queue's time; only the camera kernel is attributable
         cand = cand[:1]
     name, nbytes, lbytes, kms = max(cand, key=lambda c: c[3])
@@ -759,7 +763,8 @@ def roofline(args, wl, scene, info, ms, rays, frames_per_launch=1, views=None):
     for cand_file in PMC_FILES:
         try:
             with open(os.path.join(ROOT, cand_file)) as fh:
-                rec = json.load(fh).get(args.workload, {}).get(name, {})
+                recs = json.load(fh).get(args.workload, {})
+                rec = recs.get(name) or (recs.get("k_trace_queue", {}) if name == "k_trace_shadow_direct" else {})     # (records older than the direct mode)
         except (OSError, ValueError):
             continue
         if rec:
