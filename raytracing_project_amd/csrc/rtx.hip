@@ -619,12 +619,16 @@ static int device_build(rtx_scene* s, hipStream_t st, bool* fallback) {
                        s->b_par_int.as<uint32_t>(), s->b_arrived.as<uint32_t>(), dH, tri_cost);
   }
   // groups, top-down; the expected-cost plan first, two binary levels per group if that tree is too deep for the stack
-  for (int fixed = 0; fixed < 2; ++fixed) {
+  // (test hooks, read at every build: RTX_TEST_DEVICE_LEVELS = fewer group levels allowed than the traversal stack holds, so that small
+  //  meshes reach the fallbacks; RTX_TEST_DEVICE_COLLAPSE=fixed = start with the second rule)
+  const int max_levels = [] { const char* e = std::getenv("RTX_TEST_DEVICE_LEVELS"); const int v = e ? std::atoi(e) : 0; return v > 0 && v < kMaxLevels ? v : kMaxLevels; }();
+  const int first_rule = [] { const char* e = std::getenv("RTX_TEST_DEVICE_COLLAPSE"); return e && std::strcmp(e, "fixed") == 0 ? 1 : 0; }();
+  for (int fixed = first_rule; fixed < 2; ++fixed) {
     if (fixed) {
       HIP_TRY(hipMemsetAsync((char*)s->d_hdr.p + offsetof(Header, ngroups), 0, offsetof(Header, round_count) - offsetof(Header, ngroups), st));
     }
     hipLaunchKernelGGL(k_emit_seed, dim3(1), dim3(64), 0, st, s->b_queue[0].as<uint2>(), dH);
-    for (int level = 0; level < kMaxLevels; ++level) {
+    for (int level = 0; level < max_levels; ++level) {
       const size_t guess = level < 8 ? (size_t)1 << (2 * level + 2) : nreg;
       hipLaunchKernelGGL(k_emit_level, dim3(build_grid(std::min<size_t>(guess, nreg))), dim3(256), 0, st, level, s->b_queue[level & 1].as<uint2>(),
                          s->b_queue[(level + 1) & 1].as<uint2>(), dH, B, tri_cost, fixed, s->b_quads.as<BvhNode>(), s->b_nodes.as<uint4>());
@@ -634,7 +638,7 @@ static int device_build(rtx_scene* s, hipStream_t st, bool* fallback) {
     uint64_t done = 0;
     for (int r = 1; r <= kMaxRounds; ++r) done += H.round_count[r];
     if (done != (uint64_t)nreg - 1) { *fallback = true; return RTX_OK; }     // a binary tree taller than the rounds provided for
-    if (H.level_count[kMaxLevels] == 0) break;
+    if (H.level_count[max_levels] == 0) break;
     if (fixed) { *fallback = true; return RTX_OK; }
   }
   const uint32_t ngroups = H.ngroups;
@@ -649,7 +653,7 @@ static int device_build(rtx_scene* s, hipStream_t st, bool* fallback) {
   s->nwild = nwild;
   s->level_start.assign(1, 0);
   uint32_t depth = 0;
-  for (int l = 0; l < kMaxLevels && H.level_count[l]; ++l) { s->level_start.push_back(s->level_start.back() + H.level_count[l]); ++depth; }
+  for (int l = 0; l < max_levels && H.level_count[l]; ++l) { s->level_start.push_back(s->level_start.back() + H.level_count[l]); ++depth; }
   s->level_identity = true; s->refit_ready = true;
   s->bvh = BvhBuildResult();
   s->bvh.quad_depth = depth; s->bvh.quad_slots = H.nslots; s->bvh.nleaves = H.nleaves;

@@ -55,6 +55,11 @@ def test_argument_validation(api):
     rc = L.rtx_trace_closest(s.h, api.fp(v), api.fp(v), 1, api.fp(t), None, None, None, None)
     assert rc == -2 and b"not committed" in L.rtx_last_error()
     assert L.rtx_scene_commit(s.h, 99) < 0          # no such device (or no GPU at all): loud error, no fallback
+    # the GPU builder is asked for with a flag, and there is no host stand-in for it: an update before a commit is refused
+    s.set_flags(api.FLAG_DEVICE_BUILD)
+    assert L.rtx_scene_update_vertices(s.h, api.fp(v), 3, api.UPDATE_REFIT) == -2 and b"not committed" in L.rtx_last_error()
+    assert L.rtx_scene_update_vertices(s.h, None, 3, api.UPDATE_REFIT) == -1
+    assert L.rtx_scene_set_flags(s.h, 1 << 20) == -1 and b"unknown flag" in L.rtx_last_error()
     assert L.rtx_scene_destroy(None) == 0
 
 
