@@ -508,7 +508,10 @@ def main():
         if verify is not None:
             result["verify"] = verify
     if rank == 0 and world == 1 and pipelined and not args.no_extras:
-        result["device_build"] = device_build_figures(api, torch, wl, scene, info, opts, rect, lambda k: cams_of(k)[0], sets[0])
+        try:        # (an extra: whatever happens in it, the line above is what was measured)
+            result["device_build"] = device_build_figures(api, torch, wl, scene, info, opts, rect, lambda k: cams_of(k)[0], sets[0])
+        except Exception as e:  # noqa: BLE001
+            result["device_build"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0 and rehearse:
         result["config"]["rehearsal"] = True
         if pipelined:      # the reassembled parts against one full-frame render of the same camera, bit for bit
