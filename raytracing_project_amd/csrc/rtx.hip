@@ -589,6 +589,7 @@ static int device_build(rtx_scene* s, hipStream_t st, bool* fallback) {
   if (int rc = s->b_sort_tmp.ensure(std::max<size_t>(tmp_bytes, 16))) return rc;
   HIP_TRY(hipcub::DeviceRadixSort::SortPairs(s->b_sort_tmp.p, tmp_bytes, s->b_keys[0].as<uint64_t>(), s->b_keys[1].as<uint64_t>(), s->b_vals.as<uint32_t>(),
                                              s->d_tri_face.as<uint32_t>(), (int)ntris, 0, 64, st));
+  HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(&H, s->d_hdr.p, sizeof H, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   const uint32_t nwild = H.nwild, nreg = ntris - nwild;
@@ -633,6 +634,7 @@ static int device_build(rtx_scene* s, hipStream_t st, bool* fallback) {
       hipLaunchKernelGGL(k_emit_level, dim3(build_grid(std::min<size_t>(guess, nreg))), dim3(256), 0, st, level, s->b_queue[level & 1].as<uint2>(),
                          s->b_queue[(level + 1) & 1].as<uint2>(), dH, B, tri_cost, fixed, s->b_quads.as<BvhNode>(), s->b_nodes.as<uint4>());
     }
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&H, s->d_hdr.p, sizeof H, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     uint64_t done = 0;
@@ -661,7 +663,9 @@ static int device_build(rtx_scene* s, hipStream_t st, bool* fallback) {
   auto t1 = std::chrono::steady_clock::now();
   s->device_build_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
   rtx_scene_info& in = s->info;
+  const rtx_scene_info was = in;             // (a rebuild of a committed scene: spheres, lights, materials and the device footprint stay what they were)
   std::memset(&in, 0, sizeof in);
+  in.nspheres = was.nspheres; in.nlights = was.nlights; in.nmaterials = was.nmaterials; in.device_bytes = was.device_bytes;
   in.ntris = ntris; in.nverts = nverts; in.nnodes = ngroups * 4; in.nleaves = H.nleaves; in.max_depth = depth; in.nwild = nwild;
   in.nslots = H.nslots; in.ntop_groups = s->bvh.top_groups[kTopLevels]; in.build_ms = s->device_build_ms;
   in.build_kind = 1; in.device_build_ms = s->device_build_ms;
@@ -720,6 +724,7 @@ static int device_refit(rtx_scene* s, hipStream_t st, bool* rebuild) {
       hipLaunchKernelGGL(k_refit_level, dim3(build_grid(count)), dim3(256), 0, st, s->level_identity ? nullptr : s->d_level_groups.as<uint32_t>(), base,
                          count, s->d_quads.as<BvhNode>(), s->d_tri_box.as<float4>(), s->d_nodes.as<uint4>());
     }
+  HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(&H, s->d_hdr.p, sizeof H, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   if (H.wild_changed) { *rebuild = true; return RTX_OK; }
@@ -756,6 +761,12 @@ static int fetch_host_mirror(rtx_scene* s) {
   }
   s->host_stale = false;
   return RTX_OK;
+}
+
+// What the traversal and shading kernels read (a refit's fp32 slots, boxes and mesh copy -- d_quads, d_tri_box, d_verts ... -- come on top).
+static uint64_t device_footprint(const rtx_scene* s) {
+  return s->d_nodes.cap + s->d_tris.cap + s->d_tris_mt.cap + s->d_tri_face.cap + s->d_face_nm.cap + s->d_spheres.cap + s->d_sph_mat.cap +
+         s->d_mats.cap + s->d_lights.cap + s->d_slights.cap + s->d_leafboxes.cap + s->d_leaf_faces.cap + s->d_face_pos.cap;
 }
 
 extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
@@ -930,10 +941,7 @@ extern "C" int rtx_scene_commit(rtx_scene* s, int device) {
   d.root_entry = 0;     // group 0 holds the children of the root
   rtx_scene_info& in = s->info;
   in.nspheres = d.nspheres; in.nlights = d.nlights; in.nmaterials = d.nmats;
-  in.device_bytes = s->d_nodes.cap + s->d_tris.cap + s->d_tris_mt.cap + s->d_tri_face.cap + s->d_face_nm.cap + s->d_spheres.cap +
-                    s->d_sph_mat.cap + s->d_mats.cap + s->d_lights.cap + s->d_slights.cap + s->d_leafboxes.cap +
-                    s->d_leaf_faces.cap + s->d_face_pos.cap;      // (what the traversal and shading kernels read; a refit's fp32 slots,
-                                                                 //  boxes and mesh copy -- d_quads, d_tri_box, d_verts ... -- come on top)
+  in.device_bytes = device_footprint(s);
   for (auto& per_kind : s->tune) for (rtx_scene::Tune& T : per_kind) T = rtx_scene::Tune();     // another scene on this handle: the tuner starts over
   s->committed = true;
   return RTX_OK;
@@ -991,6 +999,7 @@ static int update_vertices(rtx_scene* s, const float* verts, uint32_t nverts, in
   auto t1 = std::chrono::steady_clock::now();
   const float ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
   if (rebuild) s->info.refits = 0; else s->refit_ms = ms;
+  s->info.device_bytes = device_footprint(s);
   s->committed = true;
   return RTX_OK;
 }

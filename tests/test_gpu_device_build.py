@@ -258,6 +258,10 @@ def test_refit_equals_a_fresh_scene(api, oa, device_build):
     s.update_vertices(torch.from_numpy(nv).cuda(), api.UPDATE_REBUILD)
     assert s.info().refits == 0 and s.info().build_kind == (1 if device_build else 0)
     fresh = make(api, nv, idx, None, mats, False)
+    # (what the info says about the rest of the scene outlives a rebuild)
+    ia, ib = s.info(), fresh.info()
+    assert (ia.nlights, ia.nmaterials, ia.nspheres, ia.ntris, ia.nverts) == (ib.nlights, ib.nmaterials, ib.nspheres, ib.ntris, ib.nverts)
+    assert ia.nlights == 1 and ia.nmaterials == 1 and ia.device_bytes > 0
     same_frames(api, s, fresh, cams, (320, 200), what="rebuild")
     nv = wobble(verts, 5)
     s.update_vertices(torch.from_numpy(nv).cuda(), api.UPDATE_REFIT)
