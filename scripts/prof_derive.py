@@ -43,6 +43,11 @@ def main():
         i = args.index("--pmc-json")
         pmc_json = args[i + 1]
         del args[i:i + 2]
+    frames_per_launch = None          # (frames a render call of the profiled command carries: bench.py scales per-launch bytes by it)
+    if "--frames-per-launch" in args:
+        i = args.index("--frames-per-launch")
+        frames_per_launch = int(args[i + 1])
+        del args[i:i + 2]
     d = load(args)
     kernels = sorted({k for k, _ in d if k.startswith("k_")})
     if pmc_json:
@@ -84,6 +89,8 @@ def main():
             if not rec:
                 continue
             rec["launches_profiled"] = max([v for (kk, _), v in DISP.items() if kk == k] or [0])
+            if frames_per_launch:
+                rec["frames_per_launch"] = frames_per_launch
             if name in out and out[name]["launches_profiled"] >= rec["launches_profiled"]:
                 continue
             out[name] = rec

@@ -14,7 +14,8 @@ python3 scripts/prof_summary.py gpurun_out/prof_${TAG}_$WL > $OUT
 python3 scripts/prof_summary.py gpurun_out/mem_${TAG}_$WL >> $OUT
 python3 scripts/prof_derive.py $OUT >> $OUT.derived && cat $OUT.derived >> $OUT && rm $OUT.derived
 echo "command: python3 bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-roofline --no-extras --repeats 1 $ARGS" >> $OUT
-python3 scripts/prof_derive.py $OUT --pmc-json $WL > gpurun_out/${TAG}_${WL}_pmc.json
+# (--steps 16 --inflight 1 with the default batch: one call of 16 frames per timed repeat; RTX_PROF_FRAMES says otherwise)
+python3 scripts/prof_derive.py $OUT --pmc-json $WL --frames-per-launch ${RTX_PROF_FRAMES:-16} > gpurun_out/${TAG}_${WL}_pmc.json
 tail -8 $OUT
 # the rocprofv3 databases are tens of MB per pass; what is wanted is in the summaries (gpurun copies back at most 64 MiB)
 rm -rf gpurun_out/prof_${TAG}_$WL gpurun_out/mem_${TAG}_$WL
