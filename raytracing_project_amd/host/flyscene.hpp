@@ -11,6 +11,7 @@
 // Vector types: a small Vector3f with the Eigen spelling the callers use (x(), y(), z(),
 // operator[], + - *, dot, norm, normalized).  Eigen itself is not a dependency.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -23,6 +24,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -422,20 +424,67 @@ inline bool loadPlyFile(MeshData& mesh, const std::string& filename) {
   }
   return true;
 }
-// tucano/utils/ppmIO.hpp:130-151 with the frame's size given: data is indexed [x][y], width x height
-// values are written row by row.  Byte-identical to the reference's writer wherever that one is defined.
+// tucano/utils/ppmIO.hpp:130-151: "P3", the size, 255, then per row the numbers min(255, (int)(255 * c)) of every pixel, each followed
+// by a blank, and a newline.  The reference streams 25 million integers through operator<< for a 4K frame (2.6 s here, a thousand
+// times the frame's render); this writes the SAME BYTES from a table of the 256 usual numbers, rows formatted by up to 16 threads
+// into buffers of their own and written in order (4K: ~0.1 s).  `at(i, j)` returns the three floats of column i, row j.
+namespace detail {
+struct P3Table {
+  char text[256][4]; unsigned char len[256];
+  P3Table() {
+    for (int v = 0; v < 256; ++v) { len[v] = (unsigned char)std::snprintf(text[v], 4, "%d", v); text[v][len[v]] = ' '; ++len[v]; }   // "N " (no terminator kept)
+  }
+};
+inline char* p3_put(char* o, const P3Table& T, float c) {
+  const int v = std::min(255, (int)(255 * c));           // the reference's expression (ppmIO.hpp:141-143)
+  if (v >= 0) { std::memcpy(o, T.text[v], 4); return o + T.len[v]; }
+  return o + std::sprintf(o, "%d ", v);                  // (a channel below zero prints as a negative number there too)
+}
+template <class At>
+inline void write_p3(const std::string& filename, int width, int height, At at) {
+  static const P3Table T;
+  std::ofstream out(filename.c_str());
+  out << "P3\n" << width << " " << height << "\n255\n";
+  if (width <= 0 || height <= 0) return;
+  const size_t row_max = (size_t)width * 3 * 12 + 1;     // "-2147483648 " is the longest entry
+  const int rows_per_job = std::max(1, (int)((size_t)(8 << 20) / row_max));
+  unsigned nthreads = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+  // bands of rows, `nthreads` at a time: formatted side by side, written in order
+  for (int j0 = 0; j0 < height; j0 += rows_per_job * (int)nthreads) {
+    const int njobs = std::min<int>((int)nthreads, (height - j0 + rows_per_job - 1) / rows_per_job);
+    std::vector<std::vector<char>> buf((size_t)njobs);
+    std::vector<size_t> used((size_t)njobs, 0);
+    auto job = [&](int k) {
+      const int ja = j0 + k * rows_per_job, jb = std::min(height, ja + rows_per_job);
+      buf[(size_t)k].resize((size_t)(jb - ja) * row_max);
+      char* o = buf[(size_t)k].data();
+      for (int j = ja; j < jb; ++j) {
+        for (int i = 0; i < width; ++i) { const float* c = at(i, j); o = p3_put(o, T, c[0]); o = p3_put(o, T, c[1]); o = p3_put(o, T, c[2]); }
+        *o++ = '\n';
+      }
+      used[(size_t)k] = (size_t)(o - buf[(size_t)k].data());
+    };
+    if (njobs == 1) job(0);
+    else {
+      std::vector<std::thread> th;
+      for (int k = 0; k < njobs; ++k) th.emplace_back(job, k);
+      for (std::thread& t : th) t.join();
+    }
+    for (int k = 0; k < njobs; ++k) out.write(buf[(size_t)k].data(), (std::streamsize)used[(size_t)k]);
+  }
+}
+}  // namespace detail
+// The writer with the frame's size given: data is indexed [x][y], width x height values are written row by row.
+// Byte-identical to the reference's writer wherever that one is defined.
 inline void writePPMImageXY(const std::string& filename, const std::vector<std::vector<Vector3f>>& data, int width, int height) {
   if ((int)data.size() < width) throw RtxError(RTX_EINVAL, "writePPMImage: the frame buffer has fewer than `width` columns");
   for (int i = 0; i < width; ++i)
     if ((int)data[i].size() < height) throw RtxError(RTX_EINVAL, "writePPMImage: a frame buffer column has fewer than `height` entries");
-  std::ofstream out(filename.c_str());
-  out << "P3\n" << width << " " << height << "\n255\n";
-  for (int j = 0; j < height; ++j) {
-    for (int i = 0; i < width; ++i)
-      out << std::min(255, (int)(255 * data[i][j][0])) << " " << std::min(255, (int)(255 * data[i][j][1])) << " "
-          << std::min(255, (int)(255 * data[i][j][2])) << " ";
-    out << "\n";
-  }
+  detail::write_p3(filename, width, height, [&](int i, int j) { return data[(size_t)i][(size_t)j].v; });
+}
+// The same file from a row-major float frame (3 floats per pixel, row j at 3 * j * width): what raytraceScene holds after a render.
+inline void writePPMImageRowMajor(const std::string& filename, const float* rgb, int width, int height) {
+  detail::write_p3(filename, width, height, [&](int i, int j) { return rgb + 3 * ((size_t)j * (size_t)width + (size_t)i); });
 }
 // The reference's signature: width = data[0].size(), height = data.size(), and data[i][j] with i < width, j < height
 // -- inside the buffer only when it is square.  Anything else is refused instead of read out of bounds.
@@ -500,11 +549,12 @@ class Flyscene {
     auto t0 = std::chrono::steady_clock::now();
     Vector2i image_size(width, height);
     if (width == 0 || height == 0) image_size = flycamera.getViewportSize();
-    std::vector<std::vector<Vector3f>> pixel_data(image_size[0]);
-    for (int i = 0; i < image_size[0]; ++i) pixel_data[i].resize(image_size[1]);
-    Vector3f origin = getCenter();
-    updating_pixels(pixel_data, origin, image_size, 1, 0);       // one GPU frame instead of 16 racing threads
-    writePPMImageXY("result.ppm", pixel_data, image_size[0], image_size[1]);
+    if (image_size[0] <= 0 || image_size[1] <= 0) throw RtxError(RTX_EINVAL, "raytraceScene: bad image size");
+    // One GPU frame instead of 16 racing threads.  The reference's pixel_data is a local that only feeds the
+    // writer (src/flyscene.cpp:410-432): the file is written straight from the rendered frame, same bytes, without the
+    // 100 MB [x][y] copy of a 4K frame.
+    render_frame(image_size[0], image_size[1]);
+    writePPMImageRowMajor("result.ppm", frame.data(), image_size[0], image_size[1]);
     auto ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     std::cout << "Time elapsed: " << (long)ms << " ms" << std::endl << "ray tracing done! " << std::endl;
   }
@@ -549,6 +599,16 @@ class Flyscene {
     if ((int)pixel_data.size() < W) throw RtxError(RTX_EINVAL, "updating_pixels: pixel_data[x][y] needs image_size[0] columns (SURVEY F8)");
     for (int i = 0; i < W; ++i)
       if ((int)pixel_data[i].size() < H) throw RtxError(RTX_EINVAL, "updating_pixels: pixel_data[x][y] needs image_size[1] entries per column (SURVEY F8)");
+    render_frame(W, H);
+    for (int j = thread_id; j < H; j += number_threads)
+      for (int i = 0; i < W; ++i) {
+        const float* p = &frame[3 * ((size_t)j * W + i)];
+        pixel_data[i][j] = Vector3f(p[0], p[1], p[2]);
+      }
+  }
+  // The frame of the current camera at W x H in `frame` (row-major floats), rendered unless it is there already.
+  void render_frame(int W, int H) {
+    std::lock_guard<std::recursive_mutex> guard(mu);
     if (!spheres_added) add_reference_spheres();
     sync();
     rtx_camera cam = flycamera.raw();
@@ -568,11 +628,6 @@ class Flyscene {
       }
       frame_w = W; frame_h = H; frame_dirty = false; frame_cam = cam; ++frames_rendered;
     }
-    for (int j = thread_id; j < H; j += number_threads)
-      for (int i = 0; i < W; ++i) {
-        const float* p = &frame[3 * ((size_t)j * W + i)];
-        pixel_data[i][j] = Vector3f(p[0], p[1], p[2]);
-      }
   }
 
   // src/flyscene.cpp:587-601

@@ -1,0 +1,15 @@
+#!/bin/bash
+# scripts/facade_time.sh : Flyscene::raytraceScene end to end (render, read-back, result.ppm) at 4K on the bunny, through the C++ facade
+set -e
+T=$(mktemp -d)
+python3 - "$T" <<'PY'
+import sys, os
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import numpy as np
+from test_gpu_facade import write_obj
+z = np.load("tests/golden/scene_bunny.npz")
+fx = {k: z[k] for k in ("verts", "idx", "tri_mat", "mats")}
+write_obj(os.path.join(sys.argv[1], "scene"), fx, ["mat%d" % i for i in range(len(fx["mats"]))])
+PY
+g++ -std=c++14 -O2 -pthread scripts/cpp/facade_time.cpp -o $T/facade_time -Lraytracing_project_amd -lrtx -Wl,-rpath,$(pwd)/raytracing_project_amd
+cd $T && timeout -k 10 300 ./facade_time scene.obj 3840 2160 north_star | grep raytraceScene; ls -la result.ppm

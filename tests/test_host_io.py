@@ -152,6 +152,18 @@ def test_ppm_writer_is_byte_identical_to_the_oracle_writer(tool, oa, tmp_path):
         assert rc == 0, err
         assert oa.lib().ora_ppm_write(str(tmp_path / "e.ppm").encode(), fp(rgb), n, n, 0) == 0
         assert open(tmp_path / "o.ppm", "rb").read() == open(tmp_path / "e.ppm", "rb").read()
+    # a frame large enough for the writer's bands of rows and threads, with channels far outside [0, 1] (they print as the
+    # integers the reference's cast makes of them: negative numbers, 255)
+    w, h = 700, 1300
+    rgb = (rng.random((h, w, 3)) * 1.3 - 0.1).astype(np.float32)
+    rgb[5, 7] = (-3.0e4, 7.5e5, -0.0)
+    rgb[1299, 699] = (1.0, 0.0, 255.0)
+    with open(tmp_path / "i.bin", "wb") as f:
+        f.write(struct.pack("<2i", w, h)); f.write(rgb.tobytes())
+    rc, err = run(tool, "ppm", tmp_path / "i.bin", tmp_path / "o.ppm")
+    assert rc == 0, err
+    assert oa.lib().ora_ppm_write(str(tmp_path / "e.ppm").encode(), fp(rgb), w, h, 0) == 0
+    assert open(tmp_path / "o.ppm", "rb").read() == open(tmp_path / "e.ppm", "rb").read()
     # non-square frames (no defined behaviour in the reference): the facade's [x][y] buffer of the frame's
     # own size gives the ordinary row-major file, and the reference-signature writer refuses instead of reading outside
     for w, h in ((5, 3), (3, 8), (64, 17)):
@@ -246,7 +258,7 @@ def test_facade_vectors_convert_from_and_to_eigen(tmp_path):
         import __graft_entry__ as g
         g.build()
     exe = str(tmp_path / "eigen_interop")
-    subprocess.run(["g++", "-std=c++14", "-O2", "-ffp-contract=off", "-Wall", "-I" + inc, os.path.join(ROOT, "tests", "cpp", "eigen_interop.cpp"),
+    subprocess.run(["g++", "-std=c++14", "-O2", "-ffp-contract=off", "-Wall", "-pthread", "-I" + inc, os.path.join(ROOT, "tests", "cpp", "eigen_interop.cpp"),
                     "-o", exe, "-L" + os.path.join(ROOT, "raytracing_project_amd"), "-lrtx",
                     "-Wl,-rpath," + os.path.join(ROOT, "raytracing_project_amd")], check=True, timeout=300)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
