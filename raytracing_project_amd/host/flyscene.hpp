@@ -606,6 +606,7 @@ class Flyscene {
         pixel_data[i][j] = Vector3f(p[0], p[1], p[2]);
       }
   }
+  const float* frame_data() const { return frame.data(); }
   // The frame of the current camera at W x H in `frame` (row-major floats), rendered unless it is there already.
   void render_frame(int W, int H) {
     std::lock_guard<std::recursive_mutex> guard(mu);

@@ -12,4 +12,4 @@ fx = {k: z[k] for k in ("verts", "idx", "tri_mat", "mats")}
 write_obj(os.path.join(sys.argv[1], "scene"), fx, ["mat%d" % i for i in range(len(fx["mats"]))])
 PY
 g++ -std=c++14 -O2 -pthread scripts/cpp/facade_time.cpp -o $T/facade_time -Lraytracing_project_amd -lrtx -Wl,-rpath,$(pwd)/raytracing_project_amd
-cd $T && timeout -k 10 300 ./facade_time scene.obj 3840 2160 north_star | grep raytraceScene; ls -la result.ppm
+cd $T && timeout -k 10 300 ./facade_time scene.obj 3840 2160 north_star | grep -E "raytraceScene|frame:|initialize"; ls -la result.ppm
