@@ -12,9 +12,11 @@
 // operator[], + - *, dot, norm, normalized).  Eigen itself is not a dependency.
 #pragma once
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <ctime>
 #include <chrono>
@@ -270,6 +272,37 @@ class Scene {
   SphereRec& getSphere(int i) { return spheres[i]; }
 };
 
+namespace detail {
+// Three white-space separated plain decimal numbers ([+-]digits[.digits][e[+-]digits]) read with strtof, which is what
+// `stream >> float` ends in for such text (libstdc++ collects the characters and calls strtof in the C locale) without
+// the stream: a std::istringstream per line made the OBJ import 1.5 us per BYTE.  Fewer than three leave zeros, like failed
+// extractions; false = the line holds something else and the caller lets a stream read it.
+inline bool three_plain_floats(const char* p, float out[3]) {
+  for (int k = 0; k < 3; ++k) {
+    while (*p && std::isspace((unsigned char)*p)) ++p;
+    if (!*p) return true;
+    const char* q = p;
+    if (*q == '+' || *q == '-') ++q;
+    int digits = 0;
+    while (*q >= '0' && *q <= '9') { ++q; ++digits; }
+    if (*q == '.') { ++q; while (*q >= '0' && *q <= '9') { ++q; ++digits; } }
+    if (!digits) return false;
+    if (*q == 'e' || *q == 'E') {
+      ++q;
+      if (*q == '+' || *q == '-') ++q;
+      if (!(*q >= '0' && *q <= '9')) return false;
+      while (*q >= '0' && *q <= '9') ++q;
+    }
+    if (*q && !std::isspace((unsigned char)*q)) return false;
+    char* end = nullptr;
+    out[k] = std::strtof(p, &end);
+    if (end != q || std::isinf(out[k])) return false;     // (beyond the float range the stream stores the largest float and fails)
+    p = q;
+  }
+  return true;
+}
+}  // namespace detail
+
 // ---- OBJ + MTL import with Tucano's face order (tucano/utils/objimporter.hpp:83-284,
 // tucano/utils/mtlIO.hpp:45-125, tucano/mesh.hpp:441-468) and the P3 writer (tucano/utils/ppmIO.hpp:130-151)
 struct MeshData {
@@ -322,18 +355,26 @@ inline bool loadObjFile(MeshData& mesh, std::vector<Tucano::Material::Mtl>& mtls
       for (size_t i = 0; i < mtls.size(); ++i) if (mtls[i].getName() == name) current_mat = (int)i;
       group_mat.back() = current_mat;
     } else if (line.compare(0, 2, "v ") == 0) {
-      std::istringstream s(line.substr(2));
-      float x = 0, y = 0, z = 0;
-      s >> x; s >> y; s >> z;
-      mesh.verts.push_back(x); mesh.verts.push_back(y); mesh.verts.push_back(z);
+      float xyz[3] = {0, 0, 0};
+      if (!detail::three_plain_floats(line.c_str() + 2, xyz)) {       // anything but plain decimal numbers: the stream's own reading
+        std::istringstream s(line.substr(2));
+        xyz[0] = xyz[1] = xyz[2] = 0;
+        s >> xyz[0]; s >> xyz[1]; s >> xyz[2];
+      }
+      mesh.verts.push_back(xyz[0]); mesh.verts.push_back(xyz[1]); mesh.verts.push_back(xyz[2]);
     } else if (line.compare(0, 2, "f ") == 0) {
       // Tucano's importer pushes EVERY item of a face record onto the group's index stream and cuts the stream into
       // triples afterwards (objimporter.hpp:191-222, mesh.hpp:446-452): a record with four vertices is not a quad but
       // shifts every later triple of its group by one, one with two shifts them back.  Kept as it is -- face ids and
       // face order are the parity contract -- and pinned against the oracle's loader on such a file; feed
       // triangulated meshes.
-      std::stringstream ls(line.substr(2));
-      for (std::string e; ls >> e;) groups.back().push_back((uint32_t)(atoi(e.c_str()) - 1));
+      // (items are what `stream >> string` would cut at white space, each read with atoi: "12/3/4" is 12)
+      for (const char* q = line.c_str() + 2; *q;) {
+        while (*q && std::isspace((unsigned char)*q)) ++q;
+        if (!*q) break;
+        groups.back().push_back((uint32_t)(atoi(q) - 1));
+        while (*q && !std::isspace((unsigned char)*q)) ++q;
+      }
     }
   }
   for (size_t g = 0; g < groups.size(); ++g)

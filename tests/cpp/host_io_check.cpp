@@ -35,7 +35,7 @@ static int dump(const MeshData& m, const std::vector<Tucano::Material::Mtl>& mat
 }
 
 int main(int argc, char** argv) {
-  if (argc != 4) { std::fprintf(stderr, "usage: host_io_check obj|ply|ppm <in> <out>\n"); return 64; }
+  if (argc != 4) { std::fprintf(stderr, "usage: host_io_check obj|ply|ppm|vline <in> <out>\n"); return 64; }
   const std::string mode = argv[1];
   if (mode == "obj" || mode == "ply") {
     MeshData m;
@@ -67,6 +67,26 @@ int main(int argc, char** argv) {
     f = std::fopen(argv[3], "wb");
     if (!f) return 2;
     std::fwrite(out.data(), 4, out.size(), f);
+    std::fclose(f);
+    return 0;
+  }
+  if (mode == "vline") {
+    // every line of <in>: the three numbers the loader's fast path reads against the stream's own reading (what Tucano's importer
+    // does, objimporter.hpp:159-161), bit for bit; <out> gets "fast N stream M"
+    std::ifstream in(argv[2]);
+    int fast = 0, slow = 0;
+    for (std::string line; std::getline(in, line);) {
+      float a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+      std::istringstream ss(line);
+      ss >> b[0]; ss >> b[1]; ss >> b[2];
+      if (detail::three_plain_floats(line.c_str(), a)) {
+        ++fast;
+        if (std::memcmp(a, b, 12) != 0) { std::fprintf(stderr, "fast path differs on: %s\n", line.c_str()); return 5; }
+      } else ++slow;
+    }
+    FILE* f = std::fopen(argv[3], "w");
+    if (!f) return 2;
+    std::fprintf(f, "fast %d stream %d\n", fast, slow);
     std::fclose(f);
     return 0;
   }

@@ -140,6 +140,28 @@ def test_ply_reader_on_the_bundled_bunny(tool, tmp_path):
     assert idx.max() < len(v)
 
 
+def test_obj_vertex_fast_path_reads_what_the_stream_reads(tool, tmp_path):
+    """loadObjFile reads plain decimal numbers with strtof instead of a std::istringstream per line (2.5x faster import);
+    every other spelling goes through the stream as in Tucano's importer.  Both readings, bit for bit, on numbers in every
+    spelling printf has, and the spellings that must NOT take the fast path."""
+    rng = np.random.default_rng(11)
+    vals = np.concatenate([rng.normal(size=3000) * 10.0 ** rng.integers(-12, 12, 3000), [0.0, -0.0, 1e-45, 1.17549435e-38, 3.4028234e38, 1e-50, 123456789.123456789]])
+    fmts = ["%.9g", "%e", "%f", "%.3f", "%+.7g", "%.17g", "%.1f", "%g", "%.12e"]
+    lines = []
+    for k in range(0, len(vals) - 2, 3):
+        f = fmts[(k // 3) % len(fmts)]
+        sep = ["  ", "\t", " "][(k // 3) % 3]
+        lines.append(sep.join(f % v for v in vals[k:k + 3]) + ("  " if k % 2 else ""))
+    lines += [".5 5. +.25", "1 2", "7", "", "   ", "1e5 1E-5 1e+5", "-0 +0 0"]
+    odd = ["1e39 2 3", "-1e39 2 3", "nan 1 2", "inf 1 2", "0x10 1 2", "1.0f 2 3", "1.5-2.5 3", "1e 2 3", "abc", "1,5 2 3", "1 2 3e", ". 1 2", "- 1 2"]
+    with open(tmp_path / "v.txt", "w") as f:
+        f.write("\n".join(lines + odd) + "\n")
+    rc, err = run(tool, "vline", tmp_path / "v.txt", tmp_path / "v.out")
+    assert rc == 0, err
+    fast, slow = [int(x) for x in open(tmp_path / "v.out").read().split()[1::2]]
+    assert slow >= len(odd) and fast >= len(lines) - 8, (fast, slow)
+
+
 def test_ppm_writer_is_byte_identical_to_the_oracle_writer(tool, oa, tmp_path):
     from oracle.oracle_api import fp
     rng = np.random.default_rng(3)
