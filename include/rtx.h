@@ -100,6 +100,14 @@ typedef struct {
 const char* rtx_last_error(void);
 int rtx_device_count(void);
 
+/* Page-locked host memory for the host-pointer entry points (rtx_render, rtx_trace_closest, ...): what they return lands in it at
+ * the PCIe rate, where a pageable destination goes through the runtime's staging copies (a 4K float frame: ~10 ms of read-back
+ * against 0.4-2 ms of rendering).  No counterpart in the reference, whose frame never leaves host memory
+ * (src/flyscene.cpp:410-415); for callers that do not link HIP themselves (the C++ facade keeps its frame in it).
+ * rtx_host_alloc: *out = `bytes` bytes (at least one), RTX_EHIP without a GPU; rtx_host_free(NULL) is a no-op. */
+int rtx_host_alloc(uint64_t bytes, void** out);
+int rtx_host_free(void* p);
+
 /* Replaces the scene state Flyscene::initialize builds from a Tucano::Mesh
  * (src/flyscene.cpp:13-120; vertices/faces: dependencies/tucano/tucano/mesh.hpp:238-247,
  * 441-468).  Triangles keep the caller's order: face ids returned by queries are indices

@@ -47,7 +47,7 @@ class SceneInfo(C.Structure):
 
 
 # every symbol include/rtx.h declares
-SYMBOLS = ["rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy",
+SYMBOLS = ["rtx_last_error", "rtx_device_count", "rtx_host_alloc", "rtx_host_free", "rtx_scene_create", "rtx_scene_destroy",
            "rtx_scene_add_material", "rtx_scene_set_spheres", "rtx_scene_set_lights", "rtx_scene_build", "rtx_scene_commit",
            "rtx_scene_get_tris",
            "rtx_scene_get_info", "rtx_scene_get_bvh", "rtx_trace_closest", "rtx_trace_closest_dev",
@@ -98,6 +98,8 @@ def lib():
         L.rtx_scene_create.argtypes = [_f, C.c_uint32, _u, _i, C.c_uint32, C.POINTER(Material), C.c_uint32,
                                        C.POINTER(C.c_void_p)]
         L.rtx_scene_destroy.argtypes = [C.c_void_p]
+        L.rtx_host_alloc.argtypes = [C.c_uint64, C.POINTER(C.c_void_p)]
+        L.rtx_host_free.argtypes = [C.c_void_p]
         L.rtx_scene_add_material.argtypes = [C.c_void_p, C.POINTER(Material)]
         L.rtx_scene_set_spheres.argtypes = [C.c_void_p, _f, _i, C.c_uint32]
         L.rtx_scene_set_lights.argtypes = [C.c_void_p, _f, C.c_uint32, _f, C.c_uint32]

@@ -196,6 +196,18 @@ extern "C" int rtx_device_count(void) {
   return n;
 }
 
+extern "C" int rtx_host_alloc(uint64_t bytes, void** out) {
+  if (!out) return fail(RTX_EINVAL, "null argument");
+  *out = nullptr;
+  HIP_TRY(hipHostMalloc(out, (size_t)std::max<uint64_t>(bytes, 1), hipHostMallocDefault));
+  return RTX_OK;
+}
+extern "C" int rtx_host_free(void* p) {
+  if (!p) return RTX_OK;
+  HIP_TRY(hipHostFree(p));
+  return RTX_OK;
+}
+
 extern "C" int rtx_scene_create(const float* verts, uint32_t nverts, const uint32_t* idx, const int32_t* tri_mat,
                                 uint32_t ntris, const rtx_material* mats, uint32_t nmats, rtx_scene** out) {
   if (!out) return fail(RTX_EINVAL, "out is null");

@@ -908,7 +908,31 @@ class Flyscene {
   std::vector<uint32_t> tri_idx;
   std::vector<float> tri_verts;
   bool dirty = true, spheres_added = false, frame_dirty = true;
-  std::vector<float> frame;
+  // The rendered frame in page-locked memory (rtx_host_alloc): rtx_render's read-back then runs at the PCIe rate (a 4K frame
+  // in ~3 ms instead of ~10 through the runtime's staging copies).  Plain memory where the library has none to give.
+  struct FrameBuffer {
+    float* p = nullptr; size_t cap = 0, n = 0; bool pinned = false;
+    FrameBuffer() {}
+    FrameBuffer(const FrameBuffer&) = delete;
+    FrameBuffer& operator=(const FrameBuffer&) = delete;
+    ~FrameBuffer() { release(); }
+    void release() { if (p) { if (pinned) rtx_host_free(p); else std::free(p); } p = nullptr; cap = n = 0; }
+    void resize(size_t count) {
+      if (count > cap) {
+        release();
+        void* q = nullptr;
+        if (rtx_host_alloc((uint64_t)count * sizeof(float), &q) == RTX_OK && q) { p = (float*)q; pinned = true; }
+        else { p = (float*)std::malloc(std::max<size_t>(count, 1) * sizeof(float)); pinned = false; if (!p) throw std::bad_alloc(); }
+        cap = count;
+      }
+      n = count;
+    }
+    float* data() { return p; }
+    const float* data() const { return p; }
+    float& operator[](size_t i) { return p[i]; }
+    const float& operator[](size_t i) const { return p[i]; }
+  };
+  FrameBuffer frame;
   int frame_w = 0, frame_h = 0;
   rtx_camera frame_cam{};
   rtx_stats stats{};

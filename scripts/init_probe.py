@@ -25,3 +25,13 @@ for k in range(3):
 host = np.empty((3840 * 2160, 3), np.float32)
 for k in range(3):
     s.render(cam, api.Options(0, 1, 0, 0, 1, 0), (0, 0, 3840, 2160), True, False); lap("rtx_render 4K into host memory, call %d" % k)
+# the same call into page-locked memory (rtx_host_alloc)
+L = api.lib()
+p = C.c_void_p()
+assert L.rtx_host_alloc(3840 * 2160 * 12, C.byref(p)) == 0
+opts = api.Options(0, 1, 0, 0, 1, 0)
+for k in range(3):
+    rc = L.rtx_render(s.h, C.byref(cam), C.byref(opts), api.Rect(0, 0, 3840, 2160), C.cast(p, C.POINTER(C.c_float)), None, None)
+    assert rc == 0
+    lap("rtx_render 4K into page-locked memory, call %d" % k)
+L.rtx_host_free(p)

@@ -1,3 +1,4 @@
+#include <cstdlib>
 // A CPU stand-in for librtx's C ABI (include/rtx.h) -- TEST INFRASTRUCTURE for tests/cpp/facade_threads.cpp only, never
 // shipped, never linked into anything that claims parity.  It lets the facade's threading be exercised under
 // ThreadSanitizer on a machine without a GPU: every entry point that takes an rtx_scene touches a plain (non-atomic)
@@ -24,6 +25,8 @@ thread_local std::string g_err;
 extern "C" {
 const char* rtx_last_error(void) { return g_err.c_str(); }
 int rtx_device_count(void) { return 1; }
+int rtx_host_alloc(uint64_t bytes, void** out) { *out = std::malloc(bytes ? bytes : 1); return *out ? 0 : -1; }
+int rtx_host_free(void* p) { std::free(p); return 0; }
 int rtx_scene_create(const float*, uint32_t, const uint32_t*, const int32_t*, uint32_t ntris, const rtx_material*, uint32_t, rtx_scene** out) {
   *out = new rtx_scene(); (*out)->ntris = ntris; return 0;
 }

@@ -55,6 +55,8 @@ def test_argument_validation(api):
     rc = L.rtx_trace_closest(s.h, api.fp(v), api.fp(v), 1, api.fp(t), None, None, None, None)
     assert rc == -2 and b"not committed" in L.rtx_last_error()
     assert L.rtx_scene_commit(s.h, 99) < 0          # no such device (or no GPU at all): loud error, no fallback
+    # page-locked host memory comes from the HIP runtime: a null argument is refused, freeing nothing is fine
+    assert L.rtx_host_alloc(16, None) == -1 and L.rtx_host_free(None) == 0
     # the GPU builder is asked for with a flag, and there is no host stand-in for it: an update before a commit is refused
     s.set_flags(api.FLAG_DEVICE_BUILD)
     assert L.rtx_scene_update_vertices(s.h, api.fp(v), 3, api.UPDATE_REFIT) == -2 and b"not committed" in L.rtx_last_error()
