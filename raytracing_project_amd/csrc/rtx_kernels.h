@@ -463,7 +463,7 @@ __device__ __forceinline__ bool node_step(const DevScene& S, const TopT& top, co
   const uint32_t wnz = nz ? h3.y : h2.z, wfz = nz ? h2.z : h3.y;
   typedef float f2 __attribute__((ext_vector_type(2)));
   const f2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az}, bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
-  float tn[4]; uint32_t en[4];
+  float tn[4]; uint32_t en[4]; bool hit[4];
 #pragma unroll
   for (int k = 0; k < 4; k += 2) {
     const int s0 = 8 * k, s1 = 8 * k + 8;
@@ -480,11 +480,13 @@ __device__ __forceinline__ bool node_step(const DevScene& S, const TopT& top, co
       const float n_ = fmaxf(fmaxf(tnx[j], tny[j]), fmaxf(tnz[j], 0.0f));
       const float f_ = fminf(fminf(tfx[j], tfy[j]), fminf(tfz[j], lim));
       en[k + j] = ents[k + j];
-      tn[k + j] = (n_ <= f_) ? n_ : INFINITY;
+      hit[k + j] = n_ <= f_;
+      tn[k + j] = hit[k + j] ? n_ : INFINITY;
     }
   }
   if constexpr (!kOrdered) {
-    const bool h0 = tn[0] != INFINITY, h1 = tn[1] != INFINITY, h2 = tn[2] != INFINITY, h3 = tn[3] != INFINITY;
+    // (the comparison itself, not "entry distance is finite": one select per child less)
+    const bool h0 = hit[0], h1 = hit[1], h2 = hit[2], h3 = hit[3];
     if (sp <= StackT::kLdsEntries - 4) {
       // four unconditional LDS stores, the stack pointer advancing over the real ones; the last of them is taken at once
       stk.lds[sp * kBlock] = en[0]; sp += h0 ? 1 : 0;
