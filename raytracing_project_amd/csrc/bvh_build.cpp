@@ -10,7 +10,11 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <thread>
 
 namespace rtx {
@@ -37,19 +41,81 @@ struct Box3 {
   }
 };
 
+// A triangle as the builder moves it about: its padded box and its input index, 32 bytes.  The passes of a node's range
+// read and partition THESE, in place -- the first version permuted an index array and gathered boxes and centroids
+// through it, one cache miss per triangle and pass once the mesh outgrew the caches.
+struct Prim {
+  float lo[3], hi[3]; uint32_t id, pad_;
+  float cen(int a) const { return 0.5f * lo[a] + 0.5f * hi[a]; }
+};
 struct Ctx {
-  const float* lo;
-  const float* hi;
-  std::vector<float> cen;   // 3 per triangle
-  uint32_t* ord;
+  Prim* prim;
 };
 
-struct Task { uint32_t node, b, e; int depth; };
+// A range of the order array waiting to become a node.  `known`: its bounds came with it (the union of the parent's bins on
+// the side of the split: min / max are exact, so these are the very numbers a pass over the range would give).
+struct Task { uint32_t node, b, e; int depth; bool known; Box3 bb, cb; };
+
+// Bins of one axis: triangle boxes, centroid boxes and counts.
+struct AxisBins {
+  Box3 box[kBins], cen[kBins]; uint32_t cnt[kBins];
+  void reset() { for (int i = 0; i < kBins; ++i) { box[i].reset(); cen[i].reset(); cnt[i] = 0; } }
+  void merge(const AxisBins& o) { for (int i = 0; i < kBins; ++i) { box[i].grow(o.box[i]); cen[i].grow(o.cen[i]); cnt[i] += o.cnt[i]; } }
+};
+struct Bins3 { AxisBins ax[3]; };
+
+// n - 1 helper threads that sleep between jobs: run(f) executes f(k) for k = 0 .. n-1, k = 0 on the caller, and returns when
+// all are done.  The top of the tree hands out several hundred short jobs (bin a range, count, scatter): starting threads for
+// each would cost as much as the work.
+class Pool {
+ public:
+  explicit Pool(int n) : n_(n < 1 ? 1 : n) {
+    for (int k = 1; k < n_; ++k) th_.emplace_back([this, k] { loop(k); });
+  }
+  ~Pool() {
+    { std::lock_guard<std::mutex> g(mu_); stop_ = true; ++gen_; }
+    cv_.notify_all();
+    for (std::thread& t : th_) t.join();
+  }
+  int size() const { return n_; }
+  void run(const std::function<void(int)>& f) {
+    if (n_ == 1) { f(0); return; }
+    { std::lock_guard<std::mutex> g(mu_); job_ = &f; left_ = n_ - 1; ++gen_; }
+    cv_.notify_all();
+    f(0);
+    std::unique_lock<std::mutex> g(mu_);
+    done_.wait(g, [this] { return left_ == 0; });
+    job_ = nullptr;
+  }
+ private:
+  void loop(int k) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(int)>* f;
+      {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+        f = job_;
+      }
+      (*f)(k);
+      { std::lock_guard<std::mutex> g(mu_); if (--left_ == 0) done_.notify_one(); }
+    }
+  }
+  int n_; std::vector<std::thread> th_;
+  std::mutex mu_; std::condition_variable cv_, done_;
+  const std::function<void(int)>* job_ = nullptr; int left_ = 0; uint64_t gen_ = 0; bool stop_ = false;
+};
 
 struct SubtreeBuilder {
   const Ctx& c;
   std::vector<BvhNode>& nodes;   // nodes[root] must exist
   uint32_t nleaves = 0, max_depth = 0;
+  Pool* pool = nullptr;          // set: ranges of kParallelMin triangles and more are binned and partitioned by its threads
+  int threads = 1;               // (= pool->size())
+  std::vector<Prim> scratch;     // the parallel partition's copy of a range
+  static constexpr uint32_t kParallelMin = 1u << 13;
   SubtreeBuilder(const Ctx& ctx, std::vector<BvhNode>& n) : c(ctx), nodes(n) {}
 
   static int levels_needed(uint32_t count) {
@@ -64,37 +130,72 @@ struct SubtreeBuilder {
     std::memcpy(n.lo, bb.lo, 12); std::memcpy(n.hi, bb.hi, 12);
     n.leftFirst = b; n.count = e - b;
     // keep triangles of a leaf in ascending input-id order (cheap, helps tie handling stay local)
-    std::sort(c.ord + b, c.ord + e);
+    std::sort(c.prim + b, c.prim + e, [](const Prim& x, const Prim& y) { return x.id < y.id; });
     ++nleaves;
     max_depth = std::max<uint32_t>(max_depth, depth);
   }
 
-  // Returns the split position (b < mid < e) or 0 when the range should become a leaf.
-  uint32_t split(uint32_t b, uint32_t e, const Box3& bb, const Box3& cb, int depth) {
+  static int bin_of(float cen, float lo, float scale) {
+    int bi = (int)((cen - lo) * scale);
+    return bi < 0 ? 0 : (bi >= kBins ? kBins - 1 : bi);
+  }
+  // One pass over ord[b, e): the bins of every axis with a centroid extent (the three passes of the first version read
+  // every triangle's box three times; the boxes are gathered through the order array, so a pass is cache misses).
+  void bin_range(uint32_t b, uint32_t e, const Box3& cb, const bool use[3], const float scale[3], Bins3* out) const {
+    for (int a = 0; a < 3; ++a) if (use[a]) out->ax[a].reset();
+    for (uint32_t i = b; i < e; ++i) {
+      const Prim& P = c.prim[i];
+      const float* tl = P.lo; const float* thi = P.hi;
+      const float tc[3] = {P.cen(0), P.cen(1), P.cen(2)};
+      for (int a = 0; a < 3; ++a) {
+        if (!use[a]) continue;
+        const int bi = bin_of(tc[a], cb.lo[a], scale[a]);
+        AxisBins& B = out->ax[a];
+        B.box[bi].grow(tl, thi); B.cen[bi].grow(tc, tc); ++B.cnt[bi];
+      }
+    }
+  }
+
+  // Returns the split position (b < mid < e) or 0 when the range should become a leaf.  On a binned split the bounds of
+  // the two sides are handed back (*sides = true).
+  uint32_t split(uint32_t b, uint32_t e, const Box3& bb, const Box3& cb, int depth, bool* sides, Box3 side_bb[2], Box3 side_cb[2]) {
     const uint32_t count = e - b;
+    *sides = false;
     const bool must_balance = depth + levels_needed(count) >= kMaxDepth;
+    const bool wide = pool && threads > 1 && count >= kParallelMin;
     int best_axis = -1, best_bin = -1;
     float best_cost = FLT_MAX;
+    Bins3 bins;
+    bool use[3] = {false, false, false}; float scale[3] = {0, 0, 0};
     if (!must_balance) {
+      bool any = false;
       for (int axis = 0; axis < 3; ++axis) {
-        float ext = cb.hi[axis] - cb.lo[axis];
-        if (!(ext > 0.0f)) continue;
-        Box3 bins[kBins]; uint32_t cnt[kBins];
-        for (int i = 0; i < kBins; ++i) { bins[i].reset(); cnt[i] = 0; }
-        const float scale = kBins / ext;
-        for (uint32_t i = b; i < e; ++i) {
-          uint32_t t = c.ord[i];
-          int bi = (int)((c.cen[3 * t + axis] - cb.lo[axis]) * scale);
-          bi = bi < 0 ? 0 : (bi >= kBins ? kBins - 1 : bi);
-          bins[bi].grow(c.lo + 3 * t, c.hi + 3 * t);
-          ++cnt[bi];
+        const float ext = cb.hi[axis] - cb.lo[axis];
+        use[axis] = ext > 0.0f;
+        if (use[axis]) { scale[axis] = kBins / ext; any = true; }
+      }
+      if (any) {
+        if (wide) {
+          std::vector<Bins3> part((size_t)threads);
+          const uint32_t step = (count + (uint32_t)threads - 1) / (uint32_t)threads;
+          pool->run([&](int k) {
+            const uint32_t cb0 = std::min(e, b + (uint32_t)k * step), ce0 = std::min(e, cb0 + step);
+            bin_range(cb0, ce0, cb, use, scale, &part[(size_t)k]);
+          });
+          for (int a = 0; a < 3; ++a) if (use[a]) { bins.ax[a] = part[0].ax[a]; for (int k = 1; k < threads; ++k) bins.ax[a].merge(part[(size_t)k].ax[a]); }
+        } else {
+          bin_range(b, e, cb, use, scale, &bins);
         }
+      }
+      for (int axis = 0; axis < 3; ++axis) {
+        if (!use[axis]) continue;
+        const AxisBins& B = bins.ax[axis];
         float right_area[kBins]; uint32_t right_cnt[kBins];
         Box3 acc; acc.reset(); uint32_t n = 0;
-        for (int i = kBins - 1; i > 0; --i) { acc.grow(bins[i]); n += cnt[i]; right_area[i] = acc.half_area(); right_cnt[i] = n; }
+        for (int i = kBins - 1; i > 0; --i) { acc.grow(B.box[i]); n += B.cnt[i]; right_area[i] = acc.half_area(); right_cnt[i] = n; }
         acc.reset(); n = 0;
         for (int i = 0; i < kBins - 1; ++i) {
-          acc.grow(bins[i]); n += cnt[i];
+          acc.grow(B.box[i]); n += B.cnt[i];
           if (n == 0 || right_cnt[i + 1] == 0) continue;
           float cost = acc.half_area() * n + right_area[i + 1] * right_cnt[i + 1];
           if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = i; }
@@ -105,27 +206,58 @@ struct SubtreeBuilder {
       float parent = bb.half_area();
       float split_cost = kTravCost + (parent > 0 ? best_cost / parent : FLT_MAX);
       if (count <= (uint32_t)kMaxLeafTris && split_cost >= (float)count) return 0;
-      float ext = cb.hi[best_axis] - cb.lo[best_axis];
-      const float scale = kBins / ext, lo = cb.lo[best_axis];
+      const float sc = scale[best_axis], lo = cb.lo[best_axis];
       const int ax = best_axis, bin = best_bin;
-      const Ctx& cc = c;
-      uint32_t* mid = std::partition(c.ord + b, c.ord + e, [&](uint32_t t) {
-        int bi = (int)((cc.cen[3 * t + ax] - lo) * scale);
-        bi = bi < 0 ? 0 : (bi >= kBins ? kBins - 1 : bi);
-        return bi <= bin;
-      });
-      uint32_t m = (uint32_t)(mid - c.ord);
-      if (m > b && m < e) return m;
+      auto left_side = [&](const Prim& P) { return bin_of(P.cen(ax), lo, sc) <= bin; };
+      uint32_t m;
+      if (wide) {
+        // every thread sorts its chunk of a copy into "left" and "right", then writes both where the prefix sums say: the two
+        // sides hold the same SETS as std::partition's, in another order -- and nothing below depends on the order inside a
+        // range (bins are unions and counts, leaves sort their triangles, the median fallback breaks ties by index)
+        scratch.assign(c.prim + b, c.prim + e);
+        const uint32_t step = (count + (uint32_t)threads - 1) / (uint32_t)threads;
+        std::vector<uint32_t> nl((size_t)threads, 0);
+        pool->run([&](int k) {
+          const uint32_t c0 = std::min(count, (uint32_t)k * step), c1 = std::min(count, c0 + step);
+          uint32_t n = 0;
+          for (uint32_t i = c0; i < c1; ++i) n += left_side(scratch[i]) ? 1u : 0u;
+          nl[(size_t)k] = n;
+        });
+        std::vector<uint32_t> lpos((size_t)threads), rpos((size_t)threads);
+        uint32_t total_left = 0;
+        for (int k = 0; k < threads; ++k) total_left += nl[(size_t)k];
+        uint32_t lp = 0, rp = total_left;
+        for (int k = 0; k < threads; ++k) {
+          const uint32_t c0 = std::min(count, (uint32_t)k * step), c1 = std::min(count, c0 + step);
+          lpos[(size_t)k] = lp; rpos[(size_t)k] = rp;
+          lp += nl[(size_t)k]; rp += (c1 - c0) - nl[(size_t)k];
+        }
+        pool->run([&](int k) {
+          const uint32_t c0 = std::min(count, (uint32_t)k * step), c1 = std::min(count, c0 + step);
+          uint32_t l = lpos[(size_t)k], r = rpos[(size_t)k];
+          for (uint32_t i = c0; i < c1; ++i) { const Prim& t = scratch[i]; if (left_side(t)) c.prim[b + l++] = t; else c.prim[b + r++] = t; }
+        });
+        m = b + total_left;
+      } else {
+        Prim* mid = std::partition(c.prim + b, c.prim + e, left_side);
+        m = (uint32_t)(mid - c.prim);
+      }
+      if (m > b && m < e) {
+        const AxisBins& B = bins.ax[best_axis];
+        for (int sd = 0; sd < 2; ++sd) { side_bb[sd].reset(); side_cb[sd].reset(); }
+        for (int i = 0; i < kBins; ++i) { const int sd = i <= best_bin ? 0 : 1; side_bb[sd].grow(B.box[i]); side_cb[sd].grow(B.cen[i]); }
+        *sides = true;
+        return m;
+      }
     }
     if (count <= (uint32_t)kMaxLeafTris) return 0;
     // balanced fallback: median along the widest centroid axis (also the depth guard)
     int axis = 0;
     for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
     uint32_t m = b + count / 2;
-    const Ctx& cc = c;
-    std::nth_element(c.ord + b, c.ord + m, c.ord + e, [&](uint32_t x, uint32_t y) {
-      float cx = cc.cen[3 * x + axis], cy = cc.cen[3 * y + axis];
-      return cx < cy || (cx == cy && x < y);
+    std::nth_element(c.prim + b, c.prim + m, c.prim + e, [&](const Prim& x, const Prim& y) {
+      float cx = x.cen(axis), cy = y.cen(axis);
+      return cx < cy || (cx == cy && x.id < y.id);
     });
     return m;
   }
@@ -133,32 +265,49 @@ struct SubtreeBuilder {
   void bounds(uint32_t b, uint32_t e, Box3* bb, Box3* cb) const {
     bb->reset(); cb->reset();
     for (uint32_t i = b; i < e; ++i) {
-      uint32_t t = c.ord[i];
-      bb->grow(c.lo + 3 * t, c.hi + 3 * t);
-      cb->grow(&c.cen[3 * t], &c.cen[3 * t]);
+      const Prim& P = c.prim[i];
+      const float pc[3] = {P.cen(0), P.cen(1), P.cen(2)};
+      bb->grow(P.lo, P.hi);
+      cb->grow(pc, pc);
     }
   }
 
   // Expands node `node` over ord[b,e).  When `stop` is non-null, ranges <= stop_size are
   // not expanded but recorded as tasks (top phase).
-  void build(uint32_t node, uint32_t b, uint32_t e, int depth, std::vector<Task>* stop, uint32_t stop_size) {
+  void build(const Task& root, std::vector<Task>* stop, uint32_t stop_size) {
     std::vector<Task> stack;
-    stack.push_back({node, b, e, depth});
+    stack.push_back(root);
     while (!stack.empty()) {
       Task t = stack.back(); stack.pop_back();
       if (stop && t.e - t.b <= stop_size) { stop->push_back(t); continue; }
-      Box3 bb, cb;
-      bounds(t.b, t.e, &bb, &cb);
-      uint32_t mid = split(t.b, t.e, bb, cb, t.depth);
-      if (mid == 0) { make_leaf(t.node, t.b, t.e, bb, t.depth); continue; }
+      if (!t.known) {
+        if (pool && threads > 1 && t.e - t.b >= kParallelMin) {
+          std::vector<Box3> pb((size_t)threads), pc((size_t)threads);
+          const uint32_t count = t.e - t.b, step = (count + (uint32_t)threads - 1) / (uint32_t)threads;
+          pool->run([&](int k) {
+            const uint32_t c0 = std::min(t.e, t.b + (uint32_t)k * step), c1 = std::min(t.e, c0 + step);
+            bounds(c0, c1, &pb[(size_t)k], &pc[(size_t)k]);
+          });
+          t.bb = pb[0]; t.cb = pc[0];
+          for (int k = 1; k < threads; ++k) { t.bb.grow(pb[(size_t)k]); t.cb.grow(pc[(size_t)k]); }
+        } else {
+          bounds(t.b, t.e, &t.bb, &t.cb);
+        }
+        t.known = true;
+      }
+      bool sides = false; Box3 sbb[2], scb[2];
+      uint32_t mid = split(t.b, t.e, t.bb, t.cb, t.depth, &sides, sbb, scb);
+      if (mid == 0) { make_leaf(t.node, t.b, t.e, t.bb, t.depth); continue; }
       uint32_t left = (uint32_t)nodes.size();
       nodes.emplace_back(); nodes.emplace_back();
       BvhNode& n = nodes[t.node];
-      std::memcpy(n.lo, bb.lo, 12); std::memcpy(n.hi, bb.hi, 12);
+      std::memcpy(n.lo, t.bb.lo, 12); std::memcpy(n.hi, t.bb.hi, 12);
       n.leftFirst = left; n.count = 0;
       // right pushed first so the left subtree is laid out right after its parent pair
-      stack.push_back({left + 1, mid, t.e, t.depth + 1});
-      stack.push_back({left, t.b, mid, t.depth + 1});
+      Task r{left + 1, mid, t.e, t.depth + 1, sides, sbb[1], scb[1]};
+      Task l{left, t.b, mid, t.depth + 1, sides, sbb[0], scb[0]};
+      stack.push_back(r);
+      stack.push_back(l);
     }
   }
 };
@@ -179,18 +328,30 @@ void build_bvh(const float* tri_lo, const float* tri_hi, uint32_t ntris, int thr
     n.leftFirst = 0; n.count = 0;
     return;
   }
+  std::vector<Prim> prims(ntris);
+  for (uint32_t i = 0; i < ntris; ++i) {
+    Prim& P = prims[i];
+    for (int k = 0; k < 3; ++k) { P.lo[k] = tri_lo[3 * (size_t)i + k]; P.hi[k] = tri_hi[3 * (size_t)i + k]; }
+    P.id = i; P.pad_ = 0;
+  }
   Ctx ctx;
-  ctx.lo = tri_lo; ctx.hi = tri_hi; ctx.ord = out->order.data();
-  ctx.cen.resize((size_t)ntris * 3);
-  for (size_t i = 0; i < (size_t)ntris * 3; ++i) ctx.cen[i] = 0.5f * tri_lo[i] + 0.5f * tri_hi[i];
+  ctx.prim = prims.data();
+  struct WriteOrder {        // the order array is the ids in their final places
+    std::vector<Prim>& p; std::vector<uint32_t>& o;
+    ~WriteOrder() { for (size_t i = 0; i < p.size(); ++i) o[i] = p[i].id; }
+  } write_order{prims, out->order};
 
   if (threads < 1) threads = 1;
   std::vector<Task> tasks;
   SubtreeBuilder top(ctx, out->nodes);
   uint32_t stop_size = 0;
   if (threads > 1 && ntris > 65536) stop_size = std::max<uint32_t>(ntris / (uint32_t)(threads * 8), 8192);
-  top.build(0, 0, ntris, 0, stop_size ? &tasks : nullptr, stop_size);
+  std::unique_ptr<Pool> helpers(stop_size ? new Pool(threads) : nullptr);     // the top of the tree works on the whole mesh: its passes are shared out as well
+  top.pool = helpers.get(); top.threads = stop_size ? threads : 1;
+  Task root_task{0u, 0u, ntris, 0, false, Box3(), Box3()};
+  top.build(root_task, stop_size ? &tasks : nullptr, stop_size);
   out->nleaves = top.nleaves; out->max_depth = top.max_depth;
+  helpers.reset();
   if (tasks.empty()) return;
 
   struct Local { std::vector<BvhNode> nodes; uint32_t nleaves = 0, max_depth = 0; };
@@ -204,7 +365,9 @@ void build_bvh(const float* tri_lo, const float* tri_hi, uint32_t ntris, int thr
       L.nodes.reserve((size_t)(tasks[i].e - tasks[i].b) + 2);
       L.nodes.emplace_back();
       SubtreeBuilder sb(ctx, L.nodes);
-      sb.build(0, tasks[i].b, tasks[i].e, tasks[i].depth, nullptr, 0);
+      Task local = tasks[i];
+      local.node = 0;
+      sb.build(local, nullptr, 0);
       L.nleaves = sb.nleaves; L.max_depth = sb.max_depth;
     }
   };

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -422,7 +423,7 @@ extern "C" int rtx_scene_build(rtx_scene* s) {
   const uint32_t ntris = (uint32_t)s->tri_mat.size();
   const uint32_t nverts = (uint32_t)(s->verts.size() / 3);
   // ---- flatten: per-face constants in the reference's arithmetic (rtx_math.h)
-  std::vector<float4> tri_rec((size_t)ntris * 4);        // mesh order first, permuted below
+  std::unique_ptr<float4[]> tri_rec(new float4[std::max<size_t>((size_t)ntris * 4, 1)]);        // mesh order first, permuted below (every record is written by the face loop)
   std::vector<float4>& face_nm = s->h_face_nm;
   face_nm.assign(std::max<uint32_t>(ntris, 1), make_float4(0, 0, 0, 0));
   std::vector<float> lo, hi;               // padded boxes of the triangles that go into the BVH
@@ -440,7 +441,11 @@ extern "C" int rtx_scene_build(rtx_scene* s) {
   // (test hook: RTX_TEST_PAD_SCALE < 0 shrinks the boxes, so that the hierarchy loses hits and RTX_FLAG_VERIFY has something to find)
   const float kPadScale = [] { const char* e = std::getenv("RTX_TEST_PAD_SCALE"); return e ? (float)std::atof(e) : 1.0f; }();
   auto vert = [&](uint32_t i) { return v3(s->verts[3 * i], s->verts[3 * i + 1], s->verts[3 * i + 2]); };
-  for (uint32_t f = 0; f < ntris; ++f) {
+  const int threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+  // faces [f0, f1): records into their own places, boxes and face lists appended to the caller's vectors (a chunk per thread
+  // for large meshes, joined in face order below: the same vectors as one pass over all faces gives)
+  auto face_range = [&](uint32_t f0, uint32_t f1, std::vector<float>& lo, std::vector<float>& hi, std::vector<uint32_t>& regular, std::vector<uint32_t>& wild) {
+  for (uint32_t f = f0; f < f1; ++f) {
     const V3 a = vert(s->idx[3 * f]), b = vert(s->idx[3 * f + 1]), c = vert(s->idx[3 * f + 2]);
     const V3 nf = face_normal(a, b, c);       // tucano/mesh.hpp:461-463
     const V3 nq = normalized(nf);             // src/flyscene.cpp:839 (identity model matrix)
@@ -490,23 +495,60 @@ extern "C" int rtx_scene_build(rtx_scene* s) {
     for (int k = 0; k < 3; ++k) { lo.push_back(bl[k] - pad); hi.push_back(bh[k] + pad); }
     regular.push_back(f);
   }
+  };
+  auto tR = std::chrono::steady_clock::now();
+  if (std::getenv("RTX_BUILD_TIMING")) std::fprintf(stderr, "before the face loop %.1f ms; ", std::chrono::duration<float, std::milli>(tR - t0).count());
+  if (threads == 1 || ntris < 65536) {
+    face_range(0, ntris, lo, hi, regular, wild);
+  } else {
+    std::vector<std::vector<float>> lo_c((size_t)threads), hi_c((size_t)threads);
+    std::vector<std::vector<uint32_t>> reg_c((size_t)threads), wild_c((size_t)threads);
+    const uint32_t step = (ntris + (uint32_t)threads - 1) / (uint32_t)threads;
+    std::vector<std::thread> pool;
+    for (int k = 0; k < threads; ++k)
+      pool.emplace_back([&, k] {
+        const uint32_t f0 = std::min(ntris, (uint32_t)k * step), f1 = std::min(ntris, f0 + step);
+        lo_c[(size_t)k].reserve((size_t)(f1 - f0) * 3); hi_c[(size_t)k].reserve((size_t)(f1 - f0) * 3);
+        face_range(f0, f1, lo_c[(size_t)k], hi_c[(size_t)k], reg_c[(size_t)k], wild_c[(size_t)k]);
+      });
+    for (std::thread& t : pool) t.join();
+    for (int k = 0; k < threads; ++k) {
+      lo.insert(lo.end(), lo_c[(size_t)k].begin(), lo_c[(size_t)k].end()); hi.insert(hi.end(), hi_c[(size_t)k].begin(), hi_c[(size_t)k].end());
+      regular.insert(regular.end(), reg_c[(size_t)k].begin(), reg_c[(size_t)k].end()); wild.insert(wild.end(), wild_c[(size_t)k].begin(), wild_c[(size_t)k].end());
+    }
+  }
   // ---- BVH over the regular triangles; wild ones are appended after the leaf-ordered run
-  int threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
   const uint32_t nreg = (uint32_t)regular.size();
+  auto tA = std::chrono::steady_clock::now();
   build_bvh(lo.data(), hi.data(), nreg, threads, &s->bvh);
+  auto tB = std::chrono::steady_clock::now();
   collapse_to_quads(&s->bvh);
+  auto tC = std::chrono::steady_clock::now();
+  if (std::getenv("RTX_BUILD_TIMING")) std::fprintf(stderr, "records %.1f ms, build_bvh %.1f ms, collapse %.1f ms\n", std::chrono::duration<float, std::milli>(tA - t0).count(),
+      std::chrono::duration<float, std::milli>(tB - tA).count(), std::chrono::duration<float, std::milli>(tC - tB).count());
   for (uint32_t k = 0; k < nreg; ++k) s->bvh.order[k] = regular[s->bvh.order[k]];
   s->bvh.order.insert(s->bvh.order.end(), wild.begin(), wild.end());
   s->nwild = (uint32_t)wild.size();
   std::vector<float4>& tri_leaf = s->h_tri_leaf;
   std::vector<int32_t>& tri_face = s->h_tri_face;
-  tri_leaf.assign((size_t)ntris * 4, make_float4(0, 0, 0, 0));
+  tri_leaf.resize((size_t)ntris * 4);
   tri_face.assign(std::max<uint32_t>(ntris, 1), 0);
-  for (uint32_t k = 0; k < ntris; ++k) {
-    uint32_t f = s->bvh.order[k];
-    tri_face[k] = (int32_t)f;
-    std::memcpy(&tri_leaf[4 * (size_t)k], &tri_rec[4 * (size_t)f], 64);
+  auto permute = [&](uint32_t k0, uint32_t k1) {
+    for (uint32_t k = k0; k < k1; ++k) {
+      uint32_t f = s->bvh.order[k];
+      tri_face[k] = (int32_t)f;
+      std::memcpy(&tri_leaf[4 * (size_t)k], &tri_rec[4 * (size_t)f], 64);
+    }
+  };
+  if (threads == 1 || ntris < 65536) permute(0, ntris);
+  else {
+    const uint32_t step = (ntris + (uint32_t)threads - 1) / (uint32_t)threads;
+    std::vector<std::thread> pool;
+    for (int k = 0; k < threads; ++k) pool.emplace_back([&, k] { const uint32_t k0 = std::min(ntris, (uint32_t)k * step); permute(k0, std::min(ntris, k0 + step)); });
+    for (std::thread& t : pool) t.join();
   }
+  auto tD = std::chrono::steady_clock::now();
+  if (std::getenv("RTX_BUILD_TIMING")) std::fprintf(stderr, "leaf order %.1f ms\n", std::chrono::duration<float, std::milli>(tD - tC).count());
   // Box(Tucano::Mesh) (src/box.h:41-85): max seeded with numeric_limits<float>::min()
   float mx[3] = {1.17549435e-38f, 1.17549435e-38f, 1.17549435e-38f};
   float mn[3] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f};
