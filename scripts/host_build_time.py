@@ -3,7 +3,8 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracing_project_amd import api, scenes
 import numpy as np
-meshes = [("soup1M", scenes.soup(1000000)), ("hall262k", scenes.hall()[:2]), ("soup5M", scenes.soup(5000000, seed=0x5EED0005, h=0.012))]
+z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "scene_bunny.npz"))
+meshes = [("bunny", (z["verts"], z["idx"])), ("soup1M", scenes.soup(1000000)), ("hall262k", scenes.hall()[:2]), ("soup5M", scenes.soup(5000000, seed=0x5EED0005, h=0.012))]
 for name, (verts, idx) in meshes:
     best = None
     for k in range(3):
