@@ -2,7 +2,7 @@
 //
 // Replaces the same thing as bvh_build.cpp -- Box(mesh) + Flyscene::divideBox_KD (src/box.h:41-85,
 // src/flyscene.cpp:77-82,1110-1185) -- for meshes that change between frames, where the host's binned-SAH build
-// (0.33 s per million triangles) is a wall.  Any conservative hierarchy gives the reference's hits, because hits are
+// (0.2-0.3 s per million triangles) is a wall.  Any conservative hierarchy gives the reference's hits, because hits are
 // reduced with a (t, faceId) lexicographic minimum: what is built here differs from the host's tree in
 // quality only, never in results (tests/test_gpu_device_build.py renders both against the oracle).
 //
