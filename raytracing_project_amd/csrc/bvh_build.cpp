@@ -115,6 +115,8 @@ struct SubtreeBuilder {
   Pool* pool = nullptr;          // set: ranges of kParallelMin triangles and more are binned and partitioned by its threads
   int threads = 1;               // (= pool->size())
   std::vector<Prim> scratch;     // the parallel partition's copy of a range
+  static constexpr uint32_t kSmall = 16;   // ranges of up to this many triangles: only the bins they touch are looked at
+  Bins3 small_bins; bool small_ready = false;   // (kept clean between nodes: a small node resets what it touched)
   static constexpr uint32_t kParallelMin = 1u << 13;
   SubtreeBuilder(const Ctx& ctx, std::vector<BvhNode>& n) : c(ctx), nodes(n) {}
 
@@ -135,6 +137,11 @@ struct SubtreeBuilder {
     max_depth = std::max<uint32_t>(max_depth, depth);
   }
 
+  void clean_small(bool small, const uint8_t touched[3][kSmall], const int ntouched[3]) {
+    if (!small) return;
+    for (int a = 0; a < 3; ++a)
+      for (int j = 0; j < ntouched[a]; ++j) { const int i = touched[a][j]; AxisBins& B = small_bins.ax[a]; B.box[i].reset(); B.cen[i].reset(); B.cnt[i] = 0; }
+  }
   static int bin_of(float cen, float lo, float scale) {
     int bi = (int)((cen - lo) * scale);
     return bi < 0 ? 0 : (bi >= kBins ? kBins - 1 : bi);
@@ -165,8 +172,50 @@ struct SubtreeBuilder {
     const bool wide = pool && threads > 1 && count >= kParallelMin;
     int best_axis = -1, best_bin = -1;
     float best_cost = FLT_MAX;
-    Bins3 bins;
+    Bins3 bins_local;
+    Bins3* binsp = &bins_local;
     bool use[3] = {false, false, false}; float scale[3] = {0, 0, 0};
+    uint8_t touched[3][kSmall]; int ntouched[3] = {0, 0, 0};
+    const bool small = !must_balance && count <= kSmall;
+    if (small) {
+      // Nine nodes in ten hold a handful of triangles: their 16 bins per axis are mostly empty, and resetting and scanning
+      // all of them was most of the builder's time.  The occupied bins, in ascending order, give the same prefix and suffix
+      // unions (an empty bin adds nothing), the same costs at the positions behind an occupied bin, and the positions behind
+      // an empty bin repeat the cost before them -- never strictly smaller, so never chosen: same split, same tie-breaks.
+      if (!small_ready) { for (int a = 0; a < 3; ++a) small_bins.ax[a].reset(); small_ready = true; }
+      binsp = &small_bins;
+      for (int axis = 0; axis < 3; ++axis) {
+        const float ext = cb.hi[axis] - cb.lo[axis];
+        use[axis] = ext > 0.0f;
+        if (use[axis]) scale[axis] = kBins / ext;
+      }
+      for (uint32_t i = b; i < e; ++i) {
+        const Prim& P = c.prim[i];
+        const float tc[3] = {P.cen(0), P.cen(1), P.cen(2)};
+        for (int a = 0; a < 3; ++a) {
+          if (!use[a]) continue;
+          const int bi = bin_of(tc[a], cb.lo[a], scale[a]);
+          AxisBins& B = small_bins.ax[a];
+          if (B.cnt[bi] == 0) touched[a][ntouched[a]++] = (uint8_t)bi;
+          B.box[bi].grow(P.lo, P.hi); B.cen[bi].grow(tc, tc); ++B.cnt[bi];
+        }
+      }
+      for (int axis = 0; axis < 3; ++axis) {
+        if (!use[axis]) continue;
+        uint8_t* tb = touched[axis]; const int m = ntouched[axis];
+        for (int i = 1; i < m; ++i) { const uint8_t v = tb[i]; int j = i; while (j > 0 && tb[j - 1] > v) { tb[j] = tb[j - 1]; --j; } tb[j] = v; }
+        const AxisBins& B = small_bins.ax[axis];
+        float right_area[kSmall]; uint32_t right_cnt[kSmall];
+        Box3 acc; acc.reset(); uint32_t n = 0;
+        for (int j = m - 1; j > 0; --j) { acc.grow(B.box[tb[j]]); n += B.cnt[tb[j]]; right_area[j] = acc.half_area(); right_cnt[j] = n; }
+        acc.reset(); n = 0;
+        for (int j = 0; j + 1 < m; ++j) {
+          acc.grow(B.box[tb[j]]); n += B.cnt[tb[j]];
+          float cost = acc.half_area() * n + right_area[j + 1] * right_cnt[j + 1];
+          if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = tb[j]; }
+        }
+      }
+    } else
     if (!must_balance) {
       bool any = false;
       for (int axis = 0; axis < 3; ++axis) {
@@ -182,14 +231,14 @@ struct SubtreeBuilder {
             const uint32_t cb0 = std::min(e, b + (uint32_t)k * step), ce0 = std::min(e, cb0 + step);
             bin_range(cb0, ce0, cb, use, scale, &part[(size_t)k]);
           });
-          for (int a = 0; a < 3; ++a) if (use[a]) { bins.ax[a] = part[0].ax[a]; for (int k = 1; k < threads; ++k) bins.ax[a].merge(part[(size_t)k].ax[a]); }
+          for (int a = 0; a < 3; ++a) if (use[a]) { bins_local.ax[a] = part[0].ax[a]; for (int k = 1; k < threads; ++k) bins_local.ax[a].merge(part[(size_t)k].ax[a]); }
         } else {
-          bin_range(b, e, cb, use, scale, &bins);
+          bin_range(b, e, cb, use, scale, &bins_local);
         }
       }
       for (int axis = 0; axis < 3; ++axis) {
         if (!use[axis]) continue;
-        const AxisBins& B = bins.ax[axis];
+        const AxisBins& B = bins_local.ax[axis];
         float right_area[kBins]; uint32_t right_cnt[kBins];
         Box3 acc; acc.reset(); uint32_t n = 0;
         for (int i = kBins - 1; i > 0; --i) { acc.grow(B.box[i]); n += B.cnt[i]; right_area[i] = acc.half_area(); right_cnt[i] = n; }
@@ -205,7 +254,7 @@ struct SubtreeBuilder {
     if (best_axis >= 0) {
       float parent = bb.half_area();
       float split_cost = kTravCost + (parent > 0 ? best_cost / parent : FLT_MAX);
-      if (count <= (uint32_t)kMaxLeafTris && split_cost >= (float)count) return 0;
+      if (count <= (uint32_t)kMaxLeafTris && split_cost >= (float)count) { clean_small(small, touched, ntouched); return 0; }
       const float sc = scale[best_axis], lo = cb.lo[best_axis];
       const int ax = best_axis, bin = best_bin;
       auto left_side = [&](const Prim& P) { return bin_of(P.cen(ax), lo, sc) <= bin; };
@@ -243,13 +292,19 @@ struct SubtreeBuilder {
         m = (uint32_t)(mid - c.prim);
       }
       if (m > b && m < e) {
-        const AxisBins& B = bins.ax[best_axis];
+        const AxisBins& B = binsp->ax[best_axis];
         for (int sd = 0; sd < 2; ++sd) { side_bb[sd].reset(); side_cb[sd].reset(); }
-        for (int i = 0; i < kBins; ++i) { const int sd = i <= best_bin ? 0 : 1; side_bb[sd].grow(B.box[i]); side_cb[sd].grow(B.cen[i]); }
+        if (small) {
+          for (int j = 0; j < ntouched[best_axis]; ++j) { const int i = touched[best_axis][j]; const int sd = i <= best_bin ? 0 : 1; side_bb[sd].grow(B.box[i]); side_cb[sd].grow(B.cen[i]); }
+        } else {
+          for (int i = 0; i < kBins; ++i) { const int sd = i <= best_bin ? 0 : 1; side_bb[sd].grow(B.box[i]); side_cb[sd].grow(B.cen[i]); }
+        }
         *sides = true;
+        clean_small(small, touched, ntouched);
         return m;
       }
     }
+    clean_small(small, touched, ntouched);
     if (count <= (uint32_t)kMaxLeafTris) return 0;
     // balanced fallback: median along the widest centroid axis (also the depth guard)
     int axis = 0;
