@@ -472,28 +472,47 @@ thread_local DpPlan g_dp;
 void dp_plan(const std::vector<BvhNode>& bin) {
   const size_t n = bin.size();
   g_dp.cost.assign(4 * n, FLT_MAX); g_dp.left_k.assign(4 * n, 0);
-  std::vector<uint32_t> order; order.reserve(n);
-  std::vector<uint32_t> stack{0};
-  while (!stack.empty()) { const uint32_t x = stack.back(); stack.pop_back(); order.push_back(x); if (bin[x].count == 0) { stack.push_back(bin[x].leftFirst); stack.push_back(bin[x].leftFirst + 1); } }
-  for (size_t i = order.size(); i-- > 0;) {
-    const uint32_t x = order[i];
-    float* c = &g_dp.cost[4 * (size_t)x];
-    if (bin[x].count != 0) { c[0] = 0.0f; continue; }
+  float* cost = g_dp.cost.data(); uint8_t* left_k = g_dp.left_k.data();      // (g_dp is this thread's; the helpers below get the arrays)
+  auto node_dp = [&bin, cost, left_k](uint32_t x) {
+    float* c = &cost[4 * (size_t)x];
+    if (bin[x].count != 0) { c[0] = 0.0f; return; }
     const uint32_t l = bin[x].leftFirst, r = l + 1;
-    const float* cl = &g_dp.cost[4 * (size_t)l]; const float* cr = &g_dp.cost[4 * (size_t)r];
+    const float* cl = &cost[4 * (size_t)l]; const float* cr = &cost[4 * (size_t)r];
     for (int k = 2; k <= 4; ++k)
       for (int a = 1; a < k; ++a) {
         if (cl[a - 1] == FLT_MAX || cr[k - a - 1] == FLT_MAX) continue;
         const float v = cl[a - 1] + cr[k - a - 1];
-        if (v < c[k - 1]) { c[k - 1] = v; g_dp.left_k[4 * (size_t)x + k - 1] = (uint8_t)a; }
+        if (v < c[k - 1]) { c[k - 1] = v; left_k[4 * (size_t)x + k - 1] = (uint8_t)a; }
       }
     const float ex = bin[x].hi[0] - bin[x].lo[0], ey = bin[x].hi[1] - bin[x].lo[1], ez = bin[x].hi[2] - bin[x].lo[2];
     const float area = ex * ey + ey * ez + ez * ex;
     int bk = 2;
     for (int k = 3; k <= 4; ++k) if (c[k - 1] < c[bk - 1]) bk = k;
     c[0] = area + c[bk - 1];
-    g_dp.left_k[4 * (size_t)x] = (uint8_t)bk;
+    left_k[4 * (size_t)x] = (uint8_t)bk;
+  };
+  // children before parents: the subtree of `root`, parents after their children
+  auto subtree = [&bin, &node_dp](uint32_t root) {
+    std::vector<uint32_t> order, stack{root};
+    while (!stack.empty()) { const uint32_t x = stack.back(); stack.pop_back(); order.push_back(x); if (bin[x].count == 0) { stack.push_back(bin[x].leftFirst); stack.push_back(bin[x].leftFirst + 1); } }
+    for (size_t i = order.size(); i-- > 0;) node_dp(order[i]);
+  };
+  const int threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+  if (threads == 1 || n < (1u << 17)) { subtree(0); return; }
+  // large trees: the subtrees seven levels down on threads (a node's plan depends on its own subtree only), the top after them
+  std::vector<uint32_t> top, roots, level{0};
+  for (int d = 0; d < 7 && !level.empty(); ++d) {
+    std::vector<uint32_t> next;
+    for (uint32_t x : level) { top.push_back(x); if (bin[x].count == 0) { next.push_back(bin[x].leftFirst); next.push_back(bin[x].leftFirst + 1); } }
+    level.swap(next);
   }
+  roots.swap(level);
+  std::atomic<size_t> cursor{0};
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t)
+    pool.emplace_back([&] { for (;;) { const size_t i = cursor.fetch_add(1); if (i >= roots.size()) break; subtree(roots[i]); } });
+  for (std::thread& t : pool) t.join();
+  for (size_t i = top.size(); i-- > 0;) node_dp(top[i]);
 }
 void dp_expand(const std::vector<BvhNode>& bin, uint32_t x, int k, uint32_t cand[4], int* nc) {
   if (k == 1) { cand[(*nc)++] = x; return; }

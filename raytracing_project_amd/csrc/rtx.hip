@@ -508,14 +508,22 @@ extern "C" int rtx_scene_build(rtx_scene* s) {
     for (int k = 0; k < threads; ++k)
       pool.emplace_back([&, k] {
         const uint32_t f0 = std::min(ntris, (uint32_t)k * step), f1 = std::min(ntris, f0 + step);
-        lo_c[(size_t)k].reserve((size_t)(f1 - f0) * 3); hi_c[(size_t)k].reserve((size_t)(f1 - f0) * 3);
+        lo_c[(size_t)k].reserve((size_t)(f1 - f0) * 3); hi_c[(size_t)k].reserve((size_t)(f1 - f0) * 3); reg_c[(size_t)k].reserve(f1 - f0);
         face_range(f0, f1, lo_c[(size_t)k], hi_c[(size_t)k], reg_c[(size_t)k], wild_c[(size_t)k]);
       });
     for (std::thread& t : pool) t.join();
-    for (int k = 0; k < threads; ++k) {
-      lo.insert(lo.end(), lo_c[(size_t)k].begin(), lo_c[(size_t)k].end()); hi.insert(hi.end(), hi_c[(size_t)k].begin(), hi_c[(size_t)k].end());
-      regular.insert(regular.end(), reg_c[(size_t)k].begin(), reg_c[(size_t)k].end()); wild.insert(wild.end(), wild_c[(size_t)k].begin(), wild_c[(size_t)k].end());
-    }
+    // joined in chunk order, each chunk copied to its place by a thread
+    std::vector<size_t> at_reg((size_t)threads + 1, 0), at_wild((size_t)threads + 1, 0);
+    for (int k = 0; k < threads; ++k) { at_reg[(size_t)k + 1] = at_reg[(size_t)k] + reg_c[(size_t)k].size(); at_wild[(size_t)k + 1] = at_wild[(size_t)k] + wild_c[(size_t)k].size(); }
+    lo.resize(at_reg[(size_t)threads] * 3); hi.resize(at_reg[(size_t)threads] * 3); regular.resize(at_reg[(size_t)threads]); wild.resize(at_wild[(size_t)threads]);
+    pool.clear();
+    for (int k = 0; k < threads; ++k)
+      pool.emplace_back([&, k] {
+        const size_t r0 = at_reg[(size_t)k], nr = reg_c[(size_t)k].size(), w0 = at_wild[(size_t)k], nw = wild_c[(size_t)k].size();
+        if (nr) { std::memcpy(&lo[3 * r0], lo_c[(size_t)k].data(), nr * 12); std::memcpy(&hi[3 * r0], hi_c[(size_t)k].data(), nr * 12); std::memcpy(&regular[r0], reg_c[(size_t)k].data(), nr * 4); }
+        if (nw) std::memcpy(&wild[w0], wild_c[(size_t)k].data(), nw * 4);
+      });
+    for (std::thread& t : pool) t.join();
   }
   // ---- BVH over the regular triangles; wild ones are appended after the leaf-ordered run
   const uint32_t nreg = (uint32_t)regular.size();
