@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <atomic>
 #include <cfloat>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <condition_variable>
@@ -114,7 +116,7 @@ struct SubtreeBuilder {
   uint32_t nleaves = 0, max_depth = 0;
   Pool* pool = nullptr;          // set: ranges of kParallelMin triangles and more are binned and partitioned by its threads
   int threads = 1;               // (= pool->size())
-  std::vector<Prim> scratch;     // the parallel partition's copy of a range
+  Prim* scratch = nullptr;       // the parallel partition's copy of a range (room for the whole mesh, owned by build_bvh)
   static constexpr uint32_t kSmall = 16;   // ranges of up to this many triangles: only the bins they touch are looked at
   Bins3 small_bins; bool small_ready = false;   // (kept clean between nodes: a small node resets what it touched)
   static constexpr uint32_t kParallelMin = 1u << 13;
@@ -263,11 +265,11 @@ struct SubtreeBuilder {
         // every thread sorts its chunk of a copy into "left" and "right", then writes both where the prefix sums say: the two
         // sides hold the same SETS as std::partition's, in another order -- and nothing below depends on the order inside a
         // range (bins are unions and counts, leaves sort their triangles, the median fallback breaks ties by index)
-        scratch.assign(c.prim + b, c.prim + e);
         const uint32_t step = (count + (uint32_t)threads - 1) / (uint32_t)threads;
         std::vector<uint32_t> nl((size_t)threads, 0);
         pool->run([&](int k) {
           const uint32_t c0 = std::min(count, (uint32_t)k * step), c1 = std::min(count, c0 + step);
+          std::memcpy(scratch + c0, c.prim + b + c0, (size_t)(c1 - c0) * sizeof(Prim));
           uint32_t n = 0;
           for (uint32_t i = c0; i < c1; ++i) n += left_side(scratch[i]) ? 1u : 0u;
           nl[(size_t)k] = n;
@@ -370,9 +372,9 @@ struct SubtreeBuilder {
 }  // namespace
 
 void build_bvh(const float* tri_lo, const float* tri_hi, uint32_t ntris, int threads, BvhBuildResult* out) {
+  const auto t_begin = std::chrono::steady_clock::now();
   out->nodes.clear(); out->order.clear(); out->nleaves = 0; out->max_depth = 0;
   out->order.resize(ntris);
-  for (uint32_t i = 0; i < ntris; ++i) out->order[i] = i;
   out->nodes.reserve((size_t)ntris * 2 + 2);
   out->nodes.emplace_back();
   if (ntris == 0) {
@@ -383,30 +385,37 @@ void build_bvh(const float* tri_lo, const float* tri_hi, uint32_t ntris, int thr
     n.leftFirst = 0; n.count = 0;
     return;
   }
-  std::vector<Prim> prims(ntris);
-  for (uint32_t i = 0; i < ntris; ++i) {
-    Prim& P = prims[i];
-    for (int k = 0; k < 3; ++k) { P.lo[k] = tri_lo[3 * (size_t)i + k]; P.hi[k] = tri_hi[3 * (size_t)i + k]; }
-    P.id = i; P.pad_ = 0;
-  }
-  Ctx ctx;
-  ctx.prim = prims.data();
-  struct WriteOrder {        // the order array is the ids in their final places
-    std::vector<Prim>& p; std::vector<uint32_t>& o;
-    ~WriteOrder() { for (size_t i = 0; i < p.size(); ++i) o[i] = p[i].id; }
-  } write_order{prims, out->order};
-
   if (threads < 1) threads = 1;
-  std::vector<Task> tasks;
-  SubtreeBuilder top(ctx, out->nodes);
   uint32_t stop_size = 0;
   if (threads > 1 && ntris > 65536) stop_size = std::max<uint32_t>(ntris / (uint32_t)(threads * 8), 8192);
   std::unique_ptr<Pool> helpers(stop_size ? new Pool(threads) : nullptr);     // the top of the tree works on the whole mesh: its passes are shared out as well
-  top.pool = helpers.get(); top.threads = stop_size ? threads : 1;
+  std::unique_ptr<Prim[]> prims(new Prim[ntris]), scratch(stop_size ? new Prim[ntris] : nullptr);
+  auto fill = [&](uint32_t i0, uint32_t i1) {
+    for (uint32_t i = i0; i < i1; ++i) {
+      Prim& P = prims[i];
+      for (int k = 0; k < 3; ++k) { P.lo[k] = tri_lo[3 * (size_t)i + k]; P.hi[k] = tri_hi[3 * (size_t)i + k]; }
+      P.id = i; P.pad_ = 0;
+    }
+  };
+  if (helpers) {
+    const uint32_t step = (ntris + (uint32_t)threads - 1) / (uint32_t)threads;
+    helpers->run([&](int k) { const uint32_t i0 = std::min(ntris, (uint32_t)k * step); fill(i0, std::min(ntris, i0 + step)); });
+  } else fill(0, ntris);
+  Ctx ctx;
+  ctx.prim = prims.get();
+  struct WriteOrder {        // the order array is the ids in their final places
+    const Prim* p; std::vector<uint32_t>& o;
+    ~WriteOrder() { for (size_t i = 0; i < o.size(); ++i) o[i] = p[i].id; }
+  } write_order{prims.get(), out->order};
+
+  std::vector<Task> tasks;
+  SubtreeBuilder top(ctx, out->nodes);
+  top.pool = helpers.get(); top.threads = stop_size ? threads : 1; top.scratch = scratch.get();
   Task root_task{0u, 0u, ntris, 0, false, Box3(), Box3()};
   top.build(root_task, stop_size ? &tasks : nullptr, stop_size);
   out->nleaves = top.nleaves; out->max_depth = top.max_depth;
   helpers.reset();
+  const auto t_top = std::chrono::steady_clock::now();
   if (tasks.empty()) return;
 
   struct Local { std::vector<BvhNode> nodes; uint32_t nleaves = 0, max_depth = 0; };
@@ -429,21 +438,32 @@ void build_bvh(const float* tri_lo, const float* tri_hi, uint32_t ntris, int thr
   std::vector<std::thread> pool;
   for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
   for (auto& t : pool) t.join();
-  // stitch in task order: local node 0 -> reserved global slot, local nodes 1.. appended
-  for (size_t i = 0; i < tasks.size(); ++i) {
-    Local& L = locals[i];
-    uint32_t off = (uint32_t)out->nodes.size();
-    auto fix = [&](BvhNode n) { if (n.count == 0) n.leftFirst = off + n.leftFirst - 1; return n; };
-    bool root_internal = L.nodes.size() > 1;
-    out->nodes[tasks[i].node] = root_internal ? fix(L.nodes[0]) : L.nodes[0];
-    for (size_t k = 1; k < L.nodes.size(); ++k) {
-      BvhNode n = L.nodes[k];
+  const auto t_tasks = std::chrono::steady_clock::now();
+  struct Report { std::chrono::steady_clock::time_point a, b, c; size_t n; ~Report() { if (std::getenv("RTX_BUILD_TIMING")) std::fprintf(stderr, "[build_bvh: top %.1f ms, %zu subtrees %.1f ms, stitch %.1f ms] ",
+      std::chrono::duration<float, std::milli>(b - a).count(), n, std::chrono::duration<float, std::milli>(c - b).count(), std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - c).count()); } } report{t_begin, t_top, t_tasks, tasks.size()};
+  // stitch in task order: local node 0 -> reserved global slot, local nodes 1.. appended (places from a prefix sum, copies on threads)
+  std::vector<uint32_t> off(tasks.size() + 1);
+  off[0] = (uint32_t)out->nodes.size();
+  for (size_t i = 0; i < tasks.size(); ++i) off[i + 1] = off[i] + (uint32_t)(locals[i].nodes.size() - 1);
+  out->nodes.resize(off[tasks.size()]);
+  std::atomic<size_t> next_stitch{0};
+  auto stitch = [&]() {
+    for (;;) {
+      const size_t i = next_stitch.fetch_add(1);
+      if (i >= tasks.size()) break;
+      Local& L = locals[i];
+      const uint32_t o = off[i];
+      auto fix = [&](BvhNode n) { if (n.count == 0) n.leftFirst = o + n.leftFirst - 1; return n; };
+      const bool root_internal = L.nodes.size() > 1;
+      out->nodes[tasks[i].node] = root_internal ? fix(L.nodes[0]) : L.nodes[0];
       // a leaf has count > 0 here (ntris > 0), so count == 0 means internal
-      out->nodes.push_back(n.count == 0 ? fix(n) : n);
+      for (size_t k = 1; k < L.nodes.size(); ++k) { const BvhNode n = L.nodes[k]; out->nodes[o + k - 1] = n.count == 0 ? fix(n) : n; }
     }
-    out->nleaves += L.nleaves;
-    out->max_depth = std::max(out->max_depth, L.max_depth);
-  }
+  };
+  pool.clear();
+  for (int t = 0; t < threads; ++t) pool.emplace_back(stitch);
+  for (auto& t : pool) t.join();
+  for (size_t i = 0; i < tasks.size(); ++i) { out->nleaves += locals[i].nleaves; out->max_depth = std::max(out->max_depth, locals[i].max_depth); }
 }
 
 
